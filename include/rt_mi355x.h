@@ -1,0 +1,167 @@
+/*
+ * rt_mi355x.h -- C ABI of the MI355X (gfx950) implementation of the Soulztorm/Raytracer per-pixel tracing path.
+ *
+ * The reference has no plugin/FFI layer: its seam is the C++ class `Renderer`
+ * (RayTracer/src/Renderer.h:101-161) driven by one caller (RayTracer/src/RaytracerApp.cpp:259-366).  The entry
+ * points below are what a drop-in `Renderer` backed by the GPU binds; each one names the reference member or
+ * data it replaces.  Plain pointers and sizes only; the caller owns every host pointer (it is copied before
+ * the call returns).  A context is not thread-safe and belongs to one GPU.
+ *
+ * Return value: 0 = ok, negative = error (RT_E_*); rt_last_error() gives the message.
+ * Citations are file:line in the reference tree.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum {
+    RT_OK = 0,
+    RT_E_ARG = -1,          /* bad argument (null, out-of-range index, size mismatch) */
+    RT_E_STATE = -2,        /* call order (render before resize/camera/scene) */
+    RT_E_HIP = -3,          /* a HIP runtime call failed */
+    RT_E_NOMEM = -4,
+    RT_E_LIMIT = -5         /* beyond a stated fixed limit */
+};
+
+/* Sphere (RayTracer/src/Scene.h:10-15). */
+typedef struct { float x, y, z, radius; uint32_t material; } rt_sphere;
+
+/* Material without the display name (RayTracer/src/Scene.h:26-35). */
+typedef struct { float albedo[3]; float emission[3]; float roughness, transparency, ior; } rt_material;
+
+/* Renderer::Settings (RayTracer/src/Renderer.h:103-110) as plain ints.  `scene_mode` carries UseSphereScene
+   (0 = mesh through the KD tree, 1 = spheres) and adds 2 = both, nearest wins by the strict sphere-first compare
+   of Renderer.cpp:292-300.  `seed` seeds the per-(pixel, frame) pcg32 streams (the value Walnut::Random::Init
+   intended, Random.h:22, is 1337). */
+typedef struct {
+    int32_t  accumulate;
+    int32_t  scene_mode;
+    int32_t  use_ace;
+    int32_t  anti_aliasing;
+    uint32_t bounces;
+    uint32_t seed;
+} rt_settings;
+
+enum { RT_SCENE_MESH = 0, RT_SCENE_SPHERES = 1, RT_SCENE_BOTH = 2 };
+
+/* Host KD tree flattened for upload: what a walk of KDTreeCPU::getRootNode() (KDAccel/KDTreeCPU.cpp:73-76,
+   node fields KDAccel/KDTreeStructs.h:55-76) emits.  Children are node indices, -1 = none (a node may have
+   one child, KDTreeCPU.cpp:600-620); a node with no child is a leaf and owns leaf_idx[first .. first+count).
+   first/count of interior nodes are ignored.  Node 0 is the root. */
+typedef struct {
+    uint32_t       n_nodes;
+    const float*   center;      /* n_nodes * 3, boundingBox::center  */
+    const float*   extent;      /* n_nodes * 3, boundingBox::extends */
+    const int32_t* left;
+    const int32_t* right;
+    const int32_t* first;
+    const int32_t* count;
+    uint32_t       n_leaf_idx;
+    const int32_t* leaf_idx;    /* triangle indices */
+} rt_kd_flat;
+
+/* Work counters; a ray is one TraceRay invocation (Renderer.cpp:154). nodes_visited / tris_tested are only
+   maintained while rt_set_stats(ctx, 1). */
+typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests; } rt_counters;
+
+/* Device time of the dominant kernel, measured with HIP events on the stream it was launched on. */
+typedef struct { uint64_t launches; double total_ms; double last_ms; } rt_kernel_time;
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* Renderer::Renderer() (Renderer.cpp:16-18) on HIP device `device_id`. Returns NULL on failure. */
+rt_ctx*     rt_create(int device_id);
+void        rt_destroy(rt_ctx*);
+const char* rt_last_error(const rt_ctx*);          /* ctx may be NULL: error of the last failed rt_create */
+/* Run the context's work on `hip_stream` (a hipStream_t) instead of its own stream; NULL restores its own. */
+int         rt_set_stream(rt_ctx*, void* hip_stream);
+
+/* ---- per-frame inputs ------------------------------------------------------------------------ */
+/* Renderer::OnResize (Renderer.cpp:20-43): (re)allocates accumulation + image, no-op when unchanged. */
+int rt_resize(rt_ctx*, uint32_t width, uint32_t height);
+/* Renderer::GetSettings() fields (Renderer.h:103-111). */
+int rt_set_settings(rt_ctx*, const rt_settings*);
+/* Scene::spheres / Scene::materials (Scene.h:37-40); re-sent every frame by the UI (RaytracerApp.cpp:283-331). */
+int rt_set_spheres(rt_ctx*, const rt_sphere*, uint32_t n);
+int rt_set_materials(rt_ctx*, const rt_material*, uint32_t n);
+/* Scene::triangles + the KDTreeCPU vertex/index arrays (Scene.h:17-24,41; KDTreeCPU.cpp:26-34): verts nverts*3,
+   tri_idx ntris*3, normals9 ntris*9 (Triangle::Normals[0..2]), tri_mat ntris.  Uploaded once. */
+int rt_set_mesh(rt_ctx*, const float* verts, uint32_t nverts, const uint32_t* tri_idx,
+                const float* normals9, const uint32_t* tri_mat, uint32_t ntris);
+/* Scene::kd_tree (Scene.h:43): the flattened host tree; requires rt_set_mesh first. */
+int rt_set_kdtree(rt_ctx*, const rt_kd_flat*);
+/* Camera::GetPosition / GetInverseProjection / GetInverseView (Camera.h:15-19), column-major like glm::mat4;
+   ray directions are generated on the device exactly as Camera::RecalculateRayDirections (Camera.cpp:134-150). */
+int rt_set_camera(rt_ctx*, const float pos[3], const float inv_proj[16], const float inv_view[16]);
+/* Alternative: Camera::GetRayDirections() (Camera.h:22) computed by the host, n = width*height xyz triples.
+   Pass NULL to return to device-side generation. */
+int rt_set_ray_dirs(rt_ctx*, const float* xyz, size_t n);
+
+/* ---- multi-GPU partition (no counterpart in the reference) ---------------------------------------- */
+/* This context renders only the 16-row bands b with b % band_count == band_index (screen-tile split);
+   (0, 1) = the whole frame. */
+int rt_set_bands(rt_ctx*, uint32_t band_index, uint32_t band_count);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* Renderer::Render (Renderer.cpp:45-135) for 1-based frame index `frame_index` (m_frameindex): trace, accumulate,
+   resolve, optional AA filter.  Asynchronous on the context's stream.  frame_index == 1 restarts accumulation
+   (Renderer.cpp:55-56). */
+int rt_render(rt_ctx*, uint32_t frame_index);
+/* n consecutive Render calls (frame_index .. frame_index+n-1) in one launch; identical accumulation, only
+   the last frame's image is resolved. */
+int rt_render_frames(rt_ctx*, uint32_t frame_index, uint32_t n);
+/* Resolve only (Renderer.cpp:68-79, 84-124): rebuild the image from the accumulation buffer as if
+   `frame_index` frames had been summed (used after a cross-GPU sum of accumulation buffers). */
+int rt_resolve(rt_ctx*, uint32_t frame_index);
+int rt_sync(rt_ctx*);
+
+/* ---- outputs --------------------------------------------------------------------------------- */
+/* m_ImageData -> Walnut::Image::SetData (Renderer.cpp:134, Walnut/Image.h:23): width*height*4 floats RGBA32F,
+   row 0 first.  Synchronises. */
+int rt_read_image(rt_ctx*, float* out_rgba32f);
+/* m_AccumulationBuffer (Renderer.h:157): width*height*3 floats. */
+int rt_read_accum(rt_ctx*, float* out_rgb);
+/* closestSphereIndex / closestTriangleIndex of the primary ray (Renderer.cpp:233-237): -1 miss, sphere index,
+   or 0x40000000 | triangle index.  Recording is off until rt_set_record_ids(ctx, 1). */
+int rt_set_record_ids(rt_ctx*, int on);
+int rt_read_primary_ids(rt_ctx*, int32_t* out);
+/* Camera::GetRayDirections() as generated on the device: width*height*3 floats. */
+int rt_read_ray_dirs(rt_ctx*, float* out_xyz);
+int rt_set_stats(rt_ctx*, int on);
+int rt_read_counters(rt_ctx*, rt_counters* out);
+int rt_reset_counters(rt_ctx*);
+int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
+int rt_reset_kernel_time(rt_ctx*);
+/* Device addresses (for collectives over the buffers): accumulation is width*height float4 (rgb + unused w),
+   image is width*height float4 RGBA. */
+void* rt_device_accum(rt_ctx*);
+void* rt_device_image(rt_ctx*);
+
+/* ---- host-side helpers (CPU; mirror the reference's host code that stays on the host) ------------ */
+/* Camera (Camera.cpp:11-19,122-132): glm::perspectiveFov / lookAt / inverse in glm's evaluation order. */
+void rt_host_camera_default_forward(float fwd[3]);
+void rt_host_camera_matrices(float fov_deg, float znear, float zfar, uint32_t width, uint32_t height,
+                             const float pos[3], const float fwd[3],
+                             float proj[16], float inv_proj[16], float view[16], float inv_view[16]);
+
+/* KD build with the semantics of KDTreeCPU::constructTreeStackless (KDTreeCPU.cpp:424-632): same split decisions
+   and triangle order, produced by binned counting instead of the 297-plane sweep.  The returned tree is owned
+   by the library; `flat` points into it until rt_host_kd_free.  max_nodes guards against the builder's
+   divergence on meshes where more than 10 triangle boxes overlap (0 = no guard). */
+typedef struct rt_host_kd rt_host_kd;
+rt_host_kd* rt_host_kd_build(const float* verts, uint32_t nverts, const uint32_t* tri_idx, uint32_t ntris,
+                             uint32_t max_nodes, int nthreads);
+int         rt_host_kd_flat(const rt_host_kd*, rt_kd_flat* flat, uint32_t* depth);
+void        rt_host_kd_free(rt_host_kd*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_MI355X_H */

@@ -1,0 +1,565 @@
+// rt_api.cpp -- context, HBM residency and the C ABI (include/rt_mi355x.h) over the gfx950 kernels.
+//
+// Plays the role of the reference's Renderer object (RayTracer/src/Renderer.{h,cpp}): owns the accumulation buffer and
+// the RGBA32F frame, takes the Scene/Camera state per frame, and runs one Render per call.  The KD tree arrives as the
+// flat host tree and is re-laid out here for the device (preorder + skip links, leaf-ordered pre-gathered triangles).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_mi355x.h"
+#include "rt_device.h"
+
+extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned gx, unsigned gy, hipStream_t s);
+extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
+extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
+
+namespace {
+
+std::string g_create_error;
+
+template <class T>
+struct DevBuf {
+    T* ptr = nullptr;
+    size_t count = 0;
+    void release() { if (ptr) { (void)hipFree(ptr); ptr = nullptr; } count = 0; }
+    hipError_t resize(size_t n)
+    {
+        if (n == count && ptr) return hipSuccess;
+        release();
+        if (!n) return hipSuccess;
+        hipError_t e = hipMalloc((void**)&ptr, n * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    // ring of event pairs around the trace kernel: timing never makes the host wait for the launch it just made
+    static const int EV_RING = 64;
+    hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {};
+    unsigned ev_head = 0, ev_tail = 0;               // [tail, head) are recorded and not yet read
+    std::string error;
+
+    uint32_t width = 0, height = 0;
+    rt_settings settings{1, RT_SCENE_MESH, 1, 0, 8, 1337};    // Renderer::Settings defaults (Renderer.h:103-110)
+    bool have_camera = false;
+    float cam_pos[3]{}, inv_proj[16]{}, inv_view[16]{};
+    uint32_t band_index = 0, band_count = 1;
+    bool record_ids = false, stats = false;
+
+    uint32_t n_spheres = 0, n_materials = 0, n_nodes = 0, n_tris = 0, n_verts = 0;
+    std::vector<float> h_verts;           // kept for the tree re-layout
+    std::vector<uint32_t> h_tris;
+    std::vector<uint32_t> h_sphere_mat, h_tri_mat;
+
+    DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image;
+    DevBuf<uint32_t> d_sphere_mat;
+    DevBuf<float> d_ray_dirs, d_out_dirs;
+    DevBuf<int32_t> d_ids;
+    DevBuf<unsigned long long> d_counters;
+    bool use_host_dirs = false;
+
+    rt_kernel_time ktime{0, 0.0, 0.0};
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, expr)                                                                              \
+    do { hipError_t e_ = (expr);                                                                     \
+         if (e_ != hipSuccess) return fail((c), RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
+
+struct DeviceGuard {
+    int prev = -1; bool ok = false;
+    explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+void grid_for(const rt_ctx* c, unsigned& gx, unsigned& gy)
+{
+    gx = (c->width + RT_TILE - 1) / RT_TILE;
+    unsigned bands = (c->height + RT_TILE - 1) / RT_TILE;
+    gy = bands > c->band_index ? (bands - c->band_index + c->band_count - 1) / c->band_count : 0;
+}
+
+void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames)
+{
+    memset(&p, 0, sizeof p);
+    memcpy(p.cam_pos, c->cam_pos, sizeof p.cam_pos);
+    memcpy(p.inv_proj, c->inv_proj, sizeof p.inv_proj);
+    memcpy(p.inv_view, c->inv_view, sizeof p.inv_view);
+    p.width = c->width; p.height = c->height;
+    p.frame_first = frame_first; p.n_frames = n_frames;
+    p.seed = c->settings.seed; p.bounces = c->settings.bounces;
+    p.n_spheres = c->n_spheres; p.n_materials = c->n_materials; p.n_nodes = c->n_nodes;
+    p.band_index = c->band_index; p.band_count = c->band_count;
+    p.use_ace = c->settings.use_ace;
+    p.spheres = c->d_spheres.ptr; p.sphere_mat = c->d_sphere_mat.ptr; p.materials = c->d_materials.ptr;
+    p.nodes = c->d_nodes.ptr; p.leafrecs = c->d_leafrecs.ptr; p.trishade = c->d_trishade.ptr;
+    p.ray_dirs = c->use_host_dirs ? c->d_ray_dirs.ptr : nullptr;
+    p.accum = c->d_accum.ptr; p.image = c->d_image.ptr;
+    p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
+    p.out_dirs = nullptr;
+    p.counters = c->d_counters.ptr;
+}
+
+// Every material index a kernel can read must be in range: the kernels do not check.
+int validate_scene(rt_ctx* c, int mode)
+{
+    if (mode == RT_SCENE_SPHERES || mode == RT_SCENE_BOTH) {
+        for (uint32_t i = 0; i < c->n_spheres; ++i)
+            if (c->h_sphere_mat[i] >= c->n_materials)
+                return fail(c, RT_E_ARG, "sphere %u: material index %u out of range (%u materials)", i, c->h_sphere_mat[i], c->n_materials);
+    }
+    if (mode == RT_SCENE_MESH || mode == RT_SCENE_BOTH) {
+        if (!c->n_nodes) return fail(c, RT_E_STATE, "scene_mode %d needs a KD tree (rt_set_mesh + rt_set_kdtree)", mode);
+        for (uint32_t i = 0; i < c->n_tris; ++i)
+            if (c->h_tri_mat[i] >= c->n_materials)
+                return fail(c, RT_E_ARG, "triangle %u: material index %u out of range (%u materials)", i, c->h_tri_mat[i], c->n_materials);
+    }
+    return RT_OK;
+}
+
+// Read back finished event pairs; with `all` (or when the ring is full) wait for the unfinished ones too.
+int collect_time(rt_ctx* c, bool all)
+{
+    while (c->ev_tail != c->ev_head) {
+        const unsigned i = c->ev_tail % rt_ctx::EV_RING;
+        const bool full = c->ev_head - c->ev_tail >= (unsigned)rt_ctx::EV_RING;
+        if (!all && !full && hipEventQuery(c->ev_stop[i]) == hipErrorNotReady) break;
+        HIP_TRY(c, hipEventSynchronize(c->ev_stop[i]));
+        float ms = 0.0f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
+        c->ktime.launches++; c->ktime.total_ms += ms; c->ktime.last_ms = ms;
+        c->ev_tail++;
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rt_ctx* rt_create(int device_id)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { fail(nullptr, RT_E_HIP, "no HIP device: %s", hipGetErrorString(e)); return nullptr; }
+    if (device_id < 0 || device_id >= n) { fail(nullptr, RT_E_ARG, "device %d out of range (%d devices)", device_id, n); return nullptr; }
+    rt_ctx* c = new rt_ctx();
+    c->device = device_id;
+    DeviceGuard g(device_id);
+    bool ok = g.ok && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < rt_ctx::EV_RING; ++i)
+        ok = hipEventCreate(&c->ev_start[i]) == hipSuccess && hipEventCreate(&c->ev_stop[i]) == hipSuccess;
+    if (!ok) {
+        fail(nullptr, RT_E_HIP, "stream/event creation failed on device %d", device_id);
+        rt_destroy(c); return nullptr;
+    }
+    c->stream = c->own_stream;
+    return c;
+}
+
+void rt_destroy(rt_ctx* c)
+{
+    if (!c) return;
+    DeviceGuard g(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_spheres.release(); c->d_materials.release(); c->d_nodes.release(); c->d_leafrecs.release();
+    c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
+    c->d_ray_dirs.release(); c->d_out_dirs.release(); c->d_ids.release(); c->d_counters.release();
+    for (int i = 0; i < rt_ctx::EV_RING; ++i) {
+        if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
+        if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+    }
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int rt_set_stream(rt_ctx* c, void* hip_stream)
+{
+    if (!c) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return RT_OK;
+}
+
+int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
+{
+    if (!c) return RT_E_ARG;
+    if (!w || !h || (uint64_t)w * h > 0x7FFFFFFFull / 4) return fail(c, RT_E_ARG, "bad size %ux%u", w, h);
+    if (w == c->width && h == c->height) return RT_OK;           // Renderer.cpp:23-24
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)w * h;
+    HIP_TRY(c, c->d_accum.resize(n));
+    HIP_TRY(c, c->d_image.resize(n));
+    HIP_TRY(c, c->d_ids.resize(n));
+    const size_t groups = (size_t)((w + RT_TILE - 1) / RT_TILE) * ((h + RT_TILE - 1) / RT_TILE);
+    HIP_TRY(c, c->d_counters.resize(groups * 4));
+    HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, n * sizeof(float4), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_image.ptr, 0, n * sizeof(float4), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_ids.ptr, 0xFF, n * sizeof(int32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, groups * 4 * sizeof(unsigned long long), c->stream));
+    c->d_ray_dirs.release(); c->use_host_dirs = false;
+    c->d_out_dirs.release();
+    c->width = w; c->height = h;
+    return RT_OK;
+}
+
+int rt_set_settings(rt_ctx* c, const rt_settings* s)
+{
+    if (!c || !s) return RT_E_ARG;
+    if (s->scene_mode < 0 || s->scene_mode > 2) return fail(c, RT_E_ARG, "scene_mode %d", s->scene_mode);
+    c->settings = *s;
+    return RT_OK;
+}
+
+int rt_set_spheres(rt_ctx* c, const rt_sphere* sp, uint32_t n)
+{
+    if (!c || (n && !sp)) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    std::vector<float4> packed(n);
+    c->h_sphere_mat.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        packed[i] = make_float4(sp[i].x, sp[i].y, sp[i].z, sp[i].radius * sp[i].radius);   // Renderer.cpp:257's r*r
+        c->h_sphere_mat[i] = sp[i].material;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_spheres.resize(n));
+    HIP_TRY(c, c->d_sphere_mat.resize(n));
+    if (n) {
+        HIP_TRY(c, hipMemcpy(c->d_spheres.ptr, packed.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(c->d_sphere_mat.ptr, c->h_sphere_mat.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->n_spheres = n;
+    return RT_OK;
+}
+
+int rt_set_materials(rt_ctx* c, const rt_material* m, uint32_t n)
+{
+    if (!c || (n && !m)) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    std::vector<float4> packed(3 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        packed[3 * i] = make_float4(m[i].albedo[0], m[i].albedo[1], m[i].albedo[2], m[i].roughness);
+        packed[3 * i + 1] = make_float4(m[i].emission[0], m[i].emission[1], m[i].emission[2], m[i].transparency);
+        packed[3 * i + 2] = make_float4(m[i].ior, 0.0f, 0.0f, 0.0f);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_materials.resize(3 * (size_t)n));
+    if (n) HIP_TRY(c, hipMemcpy(c->d_materials.ptr, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->n_materials = n;
+    return RT_OK;
+}
+
+int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* tri_idx, const float* normals9,
+                const uint32_t* tri_mat, uint32_t ntris)
+{
+    if (!c || !verts || !tri_idx || !normals9 || !tri_mat || !nverts || !ntris) return fail(c, RT_E_ARG, "rt_set_mesh: null/empty input");
+    if (ntris >= 0x40000000u) return fail(c, RT_E_LIMIT, "rt_set_mesh: %u triangles exceed the 2^30 id space", ntris);
+    for (size_t i = 0; i < 3 * (size_t)ntris; ++i)
+        if (tri_idx[i] >= nverts) return fail(c, RT_E_ARG, "rt_set_mesh: vertex index %u out of range at triangle %zu", tri_idx[i], i / 3);
+    DeviceGuard g(c->device);
+    c->h_verts.assign(verts, verts + 3 * (size_t)nverts);
+    c->h_tris.assign(tri_idx, tri_idx + 3 * (size_t)ntris);
+    c->h_tri_mat.assign(tri_mat, tri_mat + ntris);
+    std::vector<float4> shade(3 * (size_t)ntris);
+    for (uint32_t t = 0; t < ntris; ++t) {
+        const float* n = normals9 + 9 * (size_t)t;
+        float mbits; memcpy(&mbits, &tri_mat[t], 4);
+        shade[3 * (size_t)t] = make_float4(n[0], n[1], n[2], n[3]);
+        shade[3 * (size_t)t + 1] = make_float4(n[4], n[5], n[6], n[7]);
+        shade[3 * (size_t)t + 2] = make_float4(n[8], mbits, 0.0f, 0.0f);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_trishade.resize(shade.size()));
+    HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->n_tris = ntris; c->n_verts = nverts;
+    c->n_nodes = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
+    return RT_OK;
+}
+
+int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
+{
+    if (!c || !kd || !kd->n_nodes || !kd->center || !kd->extent || !kd->left || !kd->right || !kd->first || !kd->count ||
+        (kd->n_leaf_idx && !kd->leaf_idx))
+        return fail(c, RT_E_ARG, "rt_set_kdtree: null/empty input");
+    if (!c->n_tris) return fail(c, RT_E_STATE, "rt_set_kdtree: call rt_set_mesh first");
+    const uint32_t N = kd->n_nodes;
+
+    // Preorder walk (left before right) with an explicit stack; every node must be reached exactly once.
+    std::vector<uint32_t> order; order.reserve(N);
+    std::vector<uint32_t> new_index(N, 0xFFFFFFFFu);
+    std::vector<uint32_t> stack; stack.push_back(0);
+    while (!stack.empty()) {
+        uint32_t n = stack.back(); stack.pop_back();
+        if (n >= N) return fail(c, RT_E_ARG, "rt_set_kdtree: child index %u out of range", n);
+        if (new_index[n] != 0xFFFFFFFFu) return fail(c, RT_E_ARG, "rt_set_kdtree: node %u reached twice (not a tree)", n);
+        new_index[n] = (uint32_t)order.size();
+        order.push_back(n);
+        if (kd->right[n] >= 0) stack.push_back((uint32_t)kd->right[n]);
+        if (kd->left[n] >= 0) stack.push_back((uint32_t)kd->left[n]);
+    }
+    const uint32_t M = (uint32_t)order.size();          // unreachable nodes are dropped
+    std::vector<uint32_t> subtree(M, 1);
+    for (uint32_t k = M; k-- > 0;) {
+        uint32_t n = order[k];
+        if (kd->left[n] >= 0) subtree[k] += subtree[new_index[(uint32_t)kd->left[n]]];
+        if (kd->right[n] >= 0) subtree[k] += subtree[new_index[(uint32_t)kd->right[n]]];
+    }
+    size_t n_refs = 0;
+    for (uint32_t k = 0; k < M; ++k) {
+        uint32_t n = order[k];
+        if (kd->left[n] < 0 && kd->right[n] < 0) {
+            if (kd->count[n] < 0 || kd->first[n] < 0 || (uint64_t)kd->first[n] + (uint64_t)kd->count[n] > kd->n_leaf_idx)
+                return fail(c, RT_E_ARG, "rt_set_kdtree: leaf %u range [%d, +%d) outside leaf_idx", n, kd->first[n], kd->count[n]);
+            n_refs += (size_t)kd->count[n];
+        }
+    }
+    if (n_refs >= 0x7FFFFFFFull / 3) return fail(c, RT_E_LIMIT, "rt_set_kdtree: %zu leaf references exceed the index space", n_refs);
+
+    std::vector<float4> nodes(2 * (size_t)M), recs(3 * n_refs);
+    size_t next_ref = 0;
+    for (uint32_t k = 0; k < M; ++k) {
+        uint32_t n = order[k];
+        uint32_t skip = k + subtree[k];
+        int32_t leaf_first = RT_LEAF_INTERIOR;
+        if (kd->left[n] < 0 && kd->right[n] < 0) {
+            leaf_first = kd->count[n] > 0 ? (int32_t)next_ref : RT_LEAF_EMPTY;
+            for (int32_t i = 0; i < kd->count[n]; ++i) {
+                int32_t tri = kd->leaf_idx[kd->first[n] + i];
+                if (tri < 0 || (uint32_t)tri >= c->n_tris) return fail(c, RT_E_ARG, "rt_set_kdtree: triangle index %d out of range in leaf %u", tri, n);
+                const uint32_t* ix = &c->h_tris[3 * (size_t)tri];
+                const float* v0 = &c->h_verts[3 * (size_t)ix[0]];
+                const float* v1 = &c->h_verts[3 * (size_t)ix[1]];
+                const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
+                // e1 = v1 - v0, e2 = v2 - v0: the first two operations of triIntersect (Intersections.cpp:58-59)
+                volatile float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+                volatile float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+                uint32_t tag = (uint32_t)tri | ((i == kd->count[n] - 1) ? 0x80000000u : 0u);
+                float tagf; memcpy(&tagf, &tag, 4);
+                recs[3 * next_ref] = make_float4(v0[0], v0[1], v0[2], e1x);
+                recs[3 * next_ref + 1] = make_float4(e1y, e1z, e2x, e2y);
+                recs[3 * next_ref + 2] = make_float4(e2z, tagf, 0.0f, 0.0f);
+                ++next_ref;
+            }
+        }
+        float skipf, leaff; memcpy(&skipf, &skip, 4); memcpy(&leaff, &leaf_first, 4);
+        nodes[2 * (size_t)k] = make_float4(kd->center[3 * (size_t)n], kd->center[3 * (size_t)n + 1], kd->center[3 * (size_t)n + 2], skipf);
+        nodes[2 * (size_t)k + 1] = make_float4(kd->extent[3 * (size_t)n], kd->extent[3 * (size_t)n + 1], kd->extent[3 * (size_t)n + 2], leaff);
+    }
+
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_nodes.resize(nodes.size()));
+    HIP_TRY(c, c->d_leafrecs.resize(recs.empty() ? 3 : recs.size()));
+    HIP_TRY(c, hipMemcpy(c->d_nodes.ptr, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->n_nodes = M;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const float inv_view[16])
+{
+    if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
+    memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
+    c->have_camera = true;
+    return RT_OK;
+}
+
+int rt_set_ray_dirs(rt_ctx* c, const float* xyz, size_t n)
+{
+    if (!c) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    if (!xyz) { c->use_host_dirs = false; return RT_OK; }
+    if (!c->width || n != (size_t)c->width * c->height) return fail(c, RT_E_ARG, "rt_set_ray_dirs: %zu directions for a %ux%u frame", n, c->width, c->height);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_ray_dirs.resize(3 * n));
+    HIP_TRY(c, hipMemcpy(c->d_ray_dirs.ptr, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice));
+    c->use_host_dirs = true;
+    return RT_OK;
+}
+
+int rt_set_bands(rt_ctx* c, uint32_t band_index, uint32_t band_count)
+{
+    if (!c || !band_count || band_index >= band_count) return fail(c, RT_E_ARG, "rt_set_bands(%u, %u)", band_index, band_count);
+    c->band_index = band_index; c->band_count = band_count;
+    return RT_OK;
+}
+
+int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
+{
+    if (!c) return RT_E_ARG;
+    if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
+    if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
+    if (!c->have_camera && !c->use_host_dirs) return fail(c, RT_E_STATE, "rt_render before rt_set_camera / rt_set_ray_dirs");
+    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render needs the camera position (rt_set_camera)");
+    const int mode = c->settings.scene_mode;
+    if (int rc = validate_scene(c, mode)) return rc;
+    DeviceGuard g(c->device);
+    if (int rc = collect_time(c, false)) return rc;
+
+    RtParams p; fill_params(c, p, frame_index, n);
+    unsigned gx, gy; grid_for(c, gx, gy);
+    if (!gy) return RT_OK;                              // this context owns no band of so small a frame
+    const unsigned ev = c->ev_head % rt_ctx::EV_RING;
+    HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
+    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, gx, gy, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
+    c->ev_head++;
+    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index + n - 1, gx, gy, c->stream));
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, uint32_t frame_index) { return rt_render_frames(c, frame_index, 1); }
+
+int rt_resolve(rt_ctx* c, uint32_t frame_index)
+{
+    if (!c || !frame_index) return RT_E_ARG;
+    if (!c->width) return fail(c, RT_E_STATE, "rt_resolve before rt_resize");
+    DeviceGuard g(c->device);
+    RtParams p; fill_params(c, p, frame_index, 1);
+    unsigned gx, gy; grid_for(c, gx, gy);
+    if (!gy) return RT_OK;
+    HIP_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* c)
+{
+    if (!c) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return collect_time(c, true);
+}
+
+int rt_read_image(rt_ctx* c, float* out)
+{
+    if (!c || !out) return RT_E_ARG;
+    if (!c->width) return fail(c, RT_E_STATE, "no frame");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_image.ptr, (size_t)c->width * c->height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    return rt_sync(c);
+}
+
+int rt_read_accum(rt_ctx* c, float* out_rgb)
+{
+    if (!c || !out_rgb) return RT_E_ARG;
+    if (!c->width) return fail(c, RT_E_STATE, "no frame");
+    DeviceGuard g(c->device);
+    const size_t n = (size_t)c->width * c->height;
+    std::vector<float4> tmp(n);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_accum.ptr, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = rt_sync(c)) return rc;
+    for (size_t i = 0; i < n; ++i) { out_rgb[3 * i] = tmp[i].x; out_rgb[3 * i + 1] = tmp[i].y; out_rgb[3 * i + 2] = tmp[i].z; }
+    return RT_OK;
+}
+
+int rt_set_record_ids(rt_ctx* c, int on) { if (!c) return RT_E_ARG; c->record_ids = on != 0; return RT_OK; }
+
+int rt_read_primary_ids(rt_ctx* c, int32_t* out)
+{
+    if (!c || !out) return RT_E_ARG;
+    if (!c->width) return fail(c, RT_E_STATE, "no frame");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemcpyAsync(out, c->d_ids.ptr, (size_t)c->width * c->height * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    return rt_sync(c);
+}
+
+int rt_read_ray_dirs(rt_ctx* c, float* out_xyz)
+{
+    if (!c || !out_xyz) return RT_E_ARG;
+    if (!c->width || !c->have_camera) return fail(c, RT_E_STATE, "rt_read_ray_dirs before rt_resize/rt_set_camera");
+    DeviceGuard g(c->device);
+    const size_t n = (size_t)c->width * c->height;
+    HIP_TRY(c, c->d_out_dirs.resize(3 * n));
+    // a zero-bounce launch generates (or passes through) the directions and touches nothing else of value:
+    // accumulation and image are saved and restored around it.
+    RtParams p; fill_params(c, p, 2, 1);
+    p.bounces = 0; p.out_dirs = c->d_out_dirs.ptr; p.primary_ids = nullptr; p.counters = nullptr;
+    DevBuf<float4> scratch_accum, scratch_image;
+    HIP_TRY(c, scratch_accum.resize(n));
+    HIP_TRY(c, scratch_image.resize(n));
+    p.accum = scratch_accum.ptr; p.image = scratch_image.ptr;
+    HIP_TRY(c, hipMemsetAsync(scratch_accum.ptr, 0, n * sizeof(float4), c->stream));
+    unsigned gx, gy; grid_for(c, gx, gy);
+    p.band_index = 0; p.band_count = 1;                 // directions for the whole frame, whatever bands we own
+    gy = (c->height + RT_TILE - 1) / RT_TILE;
+    hipError_t e = rt_launch_trace(&p, RT_MODE_SPHERES, 0, gx, gy, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, c->d_out_dirs.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    scratch_accum.release(); scratch_image.release();
+    if (e != hipSuccess) return fail(c, RT_E_HIP, "rt_read_ray_dirs: %s", hipGetErrorString(e));
+    return RT_OK;
+}
+
+int rt_set_stats(rt_ctx* c, int on) { if (!c) return RT_E_ARG; c->stats = on != 0; return RT_OK; }
+
+int rt_read_counters(rt_ctx* c, rt_counters* out)
+{
+    if (!c || !out) return RT_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (!c->d_counters.count) return RT_OK;
+    DeviceGuard g(c->device);
+    std::vector<unsigned long long> h(c->d_counters.count);
+    HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_counters.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = rt_sync(c)) return rc;
+    for (size_t i = 0; i < h.size(); i += 4) {
+        out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
+    }
+    return RT_OK;
+}
+
+int rt_reset_counters(rt_ctx* c)
+{
+    if (!c) return RT_E_ARG;
+    if (!c->d_counters.count) return RT_OK;
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int rt_get_kernel_time(rt_ctx* c, rt_kernel_time* out)
+{
+    if (!c || !out) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    if (int rc = collect_time(c, true)) return rc;
+    *out = c->ktime;
+    return RT_OK;
+}
+
+int rt_reset_kernel_time(rt_ctx* c)
+{
+    if (!c) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    if (int rc = collect_time(c, true)) return rc;
+    c->ktime = rt_kernel_time{0, 0.0, 0.0};
+    return RT_OK;
+}
+
+void* rt_device_accum(rt_ctx* c) { return c ? (void*)c->d_accum.ptr : nullptr; }
+void* rt_device_image(rt_ctx* c) { return c ? (void*)c->d_image.ptr : nullptr; }
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// rt_device.h -- data layouts shared by the host side of the library and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+#define RT_TILE 16                 // a 256-thread workgroup covers 16x16 pixels; each wave an 8x8 tile
+#define RT_ID_TRI_BIT 0x40000000
+
+#define RT_MODE_MESH    0     // rt_settings.scene_mode values
+#define RT_MODE_SPHERES 1
+#define RT_MODE_BOTH    2
+
+#define RT_LEAF_INTERIOR (-1)      // RtNode.leaf_first: not a leaf
+#define RT_LEAF_EMPTY    (-2)      // a leaf that owns no triangle
+
+// HBM layouts (all 16-byte aligned, read with dwordx4 loads):
+//
+//  nodes    : 2 x float4 per node, nodes in PREORDER (left subtree before right subtree), so the traversal order
+//             of KDTreeCPU::intersect (KDAccel/KDTreeCPU.cpp:649-708: box test, then left, then right) is
+//             "next node = i + 1 on descend, skip[i] otherwise" with no per-lane stack:
+//               [0] = { center.x, center.y, center.z, bits(skip) }       skip = index after this node's subtree
+//               [1] = { extent.x, extent.y, extent.z, bits(leaf_first) } first leaf record, or RT_LEAF_*
+//  leafrecs : 3 x float4 per (leaf, triangle) reference, leaves in preorder, triangles in the leaf's own order,
+//             vertices pre-gathered so a leaf is one contiguous run:
+//               [0] = { v0.x, v0.y, v0.z, e1.x }   e1 = v1 - v0, e2 = v2 - v0 (the first two operations of
+//               [1] = { e1.y, e1.z, e2.x, e2.y }   Intersections::triIntersect, Intersections.cpp:58-59, done once)
+//               [2] = { e2.z, bits(tri | last<<31), 0, 0 }
+//  trishade : 3 x float4 per triangle (read once per closest hit): the three corner normals + material
+//               [0] = { n0.x, n0.y, n0.z, n1.x }  [1] = { n1.y, n1.z, n2.x, n2.y }  [2] = { n2.z, bits(material), 0, 0 }
+//  spheres  : float4 { center.xyz, radius*radius } + uint32 material, index order = Scene::spheres order
+//  materials: 3 x float4 { albedo.rgb, roughness } { emission.rgb, transparency } { ior, 0, 0, 0 }
+//  accum    : float4 per pixel { r, g, b, unused }, row-major, row 0 first (m_AccumulationBuffer, Renderer.h:157)
+//  image    : float4 per pixel RGBA32F (m_ImageData, Renderer.h:156)
+
+struct RtParams {
+    float cam_pos[3];
+    float inv_proj[16];
+    float inv_view[16];
+    uint32_t width, height;
+    uint32_t frame_first, n_frames;
+    uint32_t seed, bounces;
+    uint32_t n_spheres, n_materials;
+    uint32_t n_nodes;
+    uint32_t band_index, band_count;       // screen-tile split: this launch covers bands b*band_count + band_index
+    int32_t  use_ace;
+    const float4* spheres;
+    const uint32_t* sphere_mat;
+    const float4* materials;
+    const float4* nodes;
+    const float4* leafrecs;
+    const float4* trishade;
+    const float*  ray_dirs;                 // optional host-supplied directions (xyz per pixel), else nullptr
+    float4* accum;
+    float4* image;
+    int32_t* primary_ids;                   // optional
+    float*   out_dirs;                      // optional: generated directions (verification)
+    unsigned long long* counters;           // 4 per workgroup: rays, nodes, tris, sphere tests
+};
