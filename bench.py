@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the tracing path: Mrays/s (primary + bounce) and ms/frame.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|3]
+
+A step is one Renderer::Render (one 1-spp frame) of the configured scene.  Default workload = BASELINE.json configs[1]:
+the reference application's default sphere scene at 1920x1080, 5 bounces, 64 accumulated frames.  With N > 1 (launched
+under torch.distributed.run, one rank per GPU) the frames are sample-split: every rank renders K frames of its own
+frame indices, the accumulation buffers are summed once over RCCL at the end of the timed region and rank 0 resolves the
+image; value = rays traced by all ranks / max-over-ranks time (weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel (device time from HIP events on its launch stream)
+against the bound that applies to the workload; `cpu_baseline` times the CPU oracle on a bounded sample of the same
+workload on this box's host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+# Algorithmic work per ray / per pixel-frame (stated in DESIGN.md):
+FLOPS_PER_SPHERE_RAY = lambda n_spheres: 6 + 24 * n_spheres + 120   # intersection + closest-hit/shade/scatter/roulette
+FLOPS_PER_PIXEL_RESOLVE = 40
+BYTES_PER_PIXEL_FRAME = 40          # accumulation read 12 + write 12 + RGBA32F write 16
+BYTES_PER_NODE, BYTES_PER_TRI, BYTES_PER_HIT = 32, 40, 40
+PEAK_VALU_NOFMA_TFLOPS = 39.3       # 256 CU x 64 lanes/clk x 2.4 GHz, one op per lane (no FMA, unpacked)
+PEAK_VALU_NOFMA_PACKED_TFLOPS = 78.6
+PEAK_HBM_GBS = 8000.0
+
+CONFIGS = {
+    1: dict(name="default sphere scene 1280x720, 5 bounces (BASELINE configs[0])", w=1280, h=720, bounces=5, mode=1, mesh=None),
+    2: dict(name="default sphere scene 1920x1080, 5 bounces, 64 spp (BASELINE configs[1])", w=1920, h=1080, bounces=5, mode=1, mesh=None),
+    3: dict(name="69,938-triangle displaced grid + KD tree, 1920x1080, 8 bounces (BASELINE configs[2])", w=1920, h=1080,
+            bounces=8, mode=0, mesh=("grid", 187)),
+}
+
+
+def build_scene(cfg):
+    import raytracer_amd as rt
+    from raytracer_amd import scenes
+    scene = rt.Scene()
+    scene.spheres = scenes.default_spheres()
+    mats = scenes.default_materials()
+    if cfg["mesh"]:
+        kind, n = cfg["mesh"]
+        gen = scenes.displaced_grid if kind == "grid" else scenes.cube_sphere
+        verts, tris, normals9, tri_mat, mesh_mats = gen(n, mat_offset=len(mats))
+        scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=min(16, os.cpu_count() or 1))
+        mats = np.concatenate([mats, mesh_mats])
+    scene.materials = mats
+    return scene
+
+
+def cpu_baseline(cfg, scene, cam, budget_frames):
+    """Time the oracle (CPU restatement, per-pixel-hash RNG mode) on a bounded sample of the workload."""
+    from oracle import orc
+    w, h = cfg["w"], cfg["h"]
+    threads = max(1, min(16, os.cpu_count() or 1))
+    oscene = orc.Scene()
+    oscene.set_spheres(scene.spheres); oscene.set_materials(scene.materials)
+    row_step = 1
+    if scene.kd_tree is not None:
+        oscene.set_mesh(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat)
+        oscene.import_kd(scene.kd_tree.arrays())
+        row_step = 8                                      # mesh frames are ~10x dearer: every 8th row
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    st = orc.Settings(1, cfg["mode"], 1, 0, cfg["bounces"])
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    cnt = orc.Counters()
+    t0 = time.perf_counter()
+    for f in range(1, budget_frames + 1):
+        oscene.render_frame(st, cam.GetPosition(), dirs, w, h, f, acc, img, counters=cnt, nthreads=threads, row_step=row_step)
+    dt = time.perf_counter() - t0
+    return {"value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "%d frame(s) of the same %dx%d workload%s, oracle (CPU restatement, hash RNG), %.1f s wall"
+                      % (budget_frames, w, h, "" if row_step == 1 else ", every %dth row" % row_step, dt),
+            "ms_per_frame": dt / budget_frames * 1e3 * (1 if row_step == 1 else row_step)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+
+    import torch                                   # device sync, barrier, RCCL: plumbing only
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd import dist as rtd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    w, h, K, W = cfg["w"], cfg["h"], args.steps, args.warmup
+    scene = build_scene(cfg)
+    cam = rt.Camera(70.0, 0.05, 100.0)
+    cam.OnResize(w, h)
+    r = rt.Renderer(local_rank)
+    r.download = False                               # frames stay in HBM; the host copy is priced separately
+    st = r.GetSettings()
+    st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
+    r.OnResize(w, h)
+    stream = torch.cuda.Stream()                     # one stream for the kernels and the collective that follows them
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+    r.upload(scene, cam)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # frame indices of this rank: sample split (world == 1: 1, 2, 3, ...)
+    warm = rtd.frames_for_rank(rank, world, W)
+    frames = rtd.frames_for_rank(rank, world, K, first=1)
+    acc_t = rtd.accum_tensor(r) if world > 1 else None
+
+    r.reset_accum()
+    for f in warm:
+        r.render_only(f + 1000)                      # warmup only heats caches/clocks; its sum is discarded
+    if world > 1:
+        rtd.sum_accumulation(acc_t)
+    r.sync(); torch.cuda.synchronize(); barrier()
+    r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
+    torch.cuda.synchronize(); barrier()
+
+    t0 = time.perf_counter()
+    for f in frames:                                 # every rank starts from a zeroed buffer (rt_reset_accum)
+        r.render_only(f)
+    if world > 1:
+        rtd.sum_accumulation(acc_t)
+        if rank == 0:
+            r.resolve(world * K)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    cnt = r.read_counters()
+    rays_t = torch.tensor([float(cnt.rays)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
+    dt_max, rays_total = float(dt_t.item()), float(rays_t.item())
+    kt = r.kernel_time()
+
+    if rank == 0:
+        px = w * h
+        avg_kernel_s = kt.total_ms / max(kt.launches, 1) / 1e3
+        rays_per_launch = cnt.rays / max(kt.launches, 1)
+        if cfg["mode"] == 1:
+            flops = rays_per_launch * FLOPS_PER_SPHERE_RAY(len(scene.spheres)) + px * FLOPS_PER_PIXEL_RESOLVE
+            achieved = flops / avg_kernel_s / 1e12
+            roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": _traffic_from_profile(args.config),
+                    "peak_packed": PEAK_VALU_NOFMA_PACKED_TFLOPS, "frac_packed": achieved / PEAK_VALU_NOFMA_PACKED_TFLOPS,
+                    "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
+                    "kernel": "rt_trace_kernel<spheres>", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+                    "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
+                    "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path"}
+        else:
+            # node / triangle counts of the same frames, from an untimed pass with the counting kernel
+            r.set_stats(True); r.reset_accum(); r.reset_counters()
+            for f in frames:
+                r.render_only(f)
+            c2 = r.read_counters(); r.set_stats(False)
+            per_launch = lambda v: v / max(len(frames), 1)
+            bytes_ = (per_launch(c2.nodes_visited) * BYTES_PER_NODE + per_launch(c2.tris_tested) * BYTES_PER_TRI
+                      + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
+            achieved = bytes_ / avg_kernel_s / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                    "traffic": _traffic_from_profile(args.config), "kernel": "rt_trace_kernel<mesh>",
+                    "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+                    "nodes_per_ray": c2.nodes_visited / max(c2.rays, 1), "tris_per_ray": c2.tris_tested / max(c2.rays, 1),
+                    "rays_per_launch": rays_per_launch,
+                    "note": "tree + triangles fit the 256 MiB Infinity Cache at this size: traffic is cache traffic, not HBM"}
+        out = {
+            "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["name"], "width": w, "height": h, "bounces": cfg["bounces"],
+                       "frames_per_gpu": K, "split": "sample" if world > 1 else "none",
+                       "rays_per_frame": rays_total / (K * world), "image": "resident in HBM (no D2H in the timed region)"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            n = args.cpu_frames or (4 if cfg["mode"] == 1 else 2)
+            out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _traffic_from_profile(config):
+    """HBM bytes per launch of the trace kernel from the committed PMC pass (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("config%d" % config, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -120,6 +120,9 @@ int rt_render_frames(rt_ctx*, uint32_t frame_index, uint32_t n);
 /* Resolve only (Renderer.cpp:68-79, 84-124): rebuild the image from the accumulation buffer as if
    `frame_index` frames had been summed (used after a cross-GPU sum of accumulation buffers). */
 int rt_resolve(rt_ctx*, uint32_t frame_index);
+/* Zero the accumulation buffer (the memset of Renderer.cpp:55-56) without rendering: lets a context whose first frame
+   index is not 1 (sample-split across GPUs) start from an empty sum. */
+int rt_reset_accum(rt_ctx*);
 int rt_sync(rt_ctx*);
 
 /* ---- outputs --------------------------------------------------------------------------------- */

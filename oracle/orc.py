@@ -76,6 +76,13 @@ def lib():
         L.orc_refract.argtypes = [vp, vp, vp, f32, vp, vp]
         L.orc_tonemap.argtypes = [vp, C.c_int, C.c_int, vp]
         L.orc_fnv1a.argtypes = [vp, C.c_uint64]; L.orc_fnv1a.restype = u32
+        L.orc_glm_normalize.argtypes = [vp, vp]
+        L.orc_glm_reflect.argtypes = [vp, vp, vp]
+        L.orc_glm_mix.argtypes = [vp, vp, f32, vp]
+        L.orc_glm_dot.argtypes = [vp, vp]; L.orc_glm_dot.restype = f32
+        L.orc_glm_cross.argtypes = [vp, vp, vp]
+        L.orc_glm_inverse.argtypes = [vp, vp]
+        L.orc_glm_mat_vec.argtypes = [vp, vp, vp]
         _lib = L
     return _lib
 

@@ -284,6 +284,15 @@ static inline void mat4_mul_vec4(const float* m, const float v[4], float out[4])
     }
 }
 
+/* the vector/matrix helpers themselves, exported for known-answer tests against real glm */
+void orc_glm_normalize(const float a[3], float o[3]) { v3 r = v_normalize(V(a[0], a[1], a[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void orc_glm_reflect(const float i[3], const float n[3], float o[3]) { v3 r = v_reflect(V(i[0], i[1], i[2]), V(n[0], n[1], n[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void orc_glm_mix(const float x[3], const float y[3], float a, float o[3]) { v3 r = v_mix(V(x[0], x[1], x[2]), V(y[0], y[1], y[2]), a); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+float orc_glm_dot(const float a[3], const float b[3]) { return v_dot(V(a[0], a[1], a[2]), V(b[0], b[1], b[2])); }
+void orc_glm_cross(const float a[3], const float b[3], float o[3]) { v3 r = v_cross(V(a[0], a[1], a[2]), V(b[0], b[1], b[2])); o[0] = r.x; o[1] = r.y; o[2] = r.z; }
+void orc_glm_inverse(const float m[16], float o[16]) { mat4_inverse(m, o); }
+void orc_glm_mat_vec(const float m[16], const float v[4], float o[4]) { mat4_mul_vec4(m, v, o); }
+
 void orc_camera_forward_default(float fwd[3])
 {
     /* Camera.cpp:14: glm::normalize(glm::vec3(0, -0.1, -1)); the double literals are cast to float */

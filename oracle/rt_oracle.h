@@ -106,7 +106,15 @@ int      orc_tri(const float o[3], const float d[3], const float v0[3], const fl
 int      orc_refract(const float d[3], const float n[3], const float p[3], float ior,
                      float out_o[3], float out_d[3]);                    /* Renderer.cpp:334-361 */
 void     orc_tonemap(const float rgb_in[3], int use_ace, int portable_pow, float rgb_out[3]); /* Renderer.h:63-98 */
-uint32_t orc_fnv1a(const void* data, uint64_t nbytes);
+uint32_t orc_fnv1a(const void* data, uint64_t nbytes);   /* FNV-1a folded over 32-bit words */
+/* glm 0.9.9.9 primitives as restated here (func_geometric.inl, func_common.inl, func_matrix.inl, type_mat4x4.inl) */
+void  orc_glm_normalize(const float a[3], float o[3]);
+void  orc_glm_reflect(const float i[3], const float n[3], float o[3]);
+void  orc_glm_mix(const float x[3], const float y[3], float a, float o[3]);
+float orc_glm_dot(const float a[3], const float b[3]);
+void  orc_glm_cross(const float a[3], const float b[3], float o[3]);
+void  orc_glm_inverse(const float m[16], float o[16]);
+void  orc_glm_mat_vec(const float m[16], const float v[4], float o[4]);
 
 #ifdef __cplusplus
 }

@@ -18,7 +18,7 @@ ID_TRI_BIT = 0x40000000
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_settings", "rt_set_spheres",
     "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
-    "rt_render_frames", "rt_resolve", "rt_sync", "rt_read_image", "rt_read_accum", "rt_set_record_ids",
+    "rt_render_frames", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_read_accum", "rt_set_record_ids",
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_device_accum", "rt_device_image",
     "rt_host_camera_default_forward", "rt_host_camera_matrices", "rt_host_kd_build", "rt_host_kd_flat", "rt_host_kd_free",
@@ -48,6 +48,24 @@ class RtKernelTime(C.Structure):
 _lib = None
 
 
+def _preload_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as the system one).  A process must hold ONE HIP
+    runtime, so when torch is installed its copy is loaded first -- by path, without importing torch -- and this
+    library's libamdhip64.so.7 dependency then resolves to it; a later `import torch` reuses the same file."""
+    import importlib.util
+    import sys
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -56,6 +74,7 @@ def lib():
         raise RuntimeError(
             "raytracer_amd: %s is missing -- build it with `make -C raytracer_amd/csrc` (or __graft_entry__.build()); "
             "there is no CPU fallback" % LIB_PATH)
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32, sz = C.c_void_p, C.c_uint32, C.c_int32, C.c_float, C.c_size_t
     sig = {
@@ -66,7 +85,7 @@ def lib():
         "rt_set_kdtree": ([vp, vp], C.c_int), "rt_set_camera": ([vp, vp, vp, vp], C.c_int),
         "rt_set_ray_dirs": ([vp, vp, sz], C.c_int), "rt_set_bands": ([vp, u32, u32], C.c_int),
         "rt_render": ([vp, u32], C.c_int), "rt_render_frames": ([vp, u32, u32], C.c_int),
-        "rt_resolve": ([vp, u32], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int),
+        "rt_resolve": ([vp, u32], C.c_int), "rt_reset_accum": ([vp], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int),
         "rt_read_accum": ([vp, vp], C.c_int), "rt_set_record_ids": ([vp, C.c_int], C.c_int),
         "rt_read_primary_ids": ([vp, vp], C.c_int), "rt_read_ray_dirs": ([vp, vp], C.c_int),
         "rt_set_stats": ([vp, C.c_int], C.c_int), "rt_read_counters": ([vp, vp], C.c_int),

@@ -447,6 +447,15 @@ int rt_resolve(rt_ctx* c, uint32_t frame_index)
     return RT_OK;
 }
 
+int rt_reset_accum(rt_ctx* c)
+{
+    if (!c) return RT_E_ARG;
+    if (!c->width) return fail(c, RT_E_STATE, "rt_reset_accum before rt_resize");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, (size_t)c->width * c->height * sizeof(float4), c->stream));
+    return RT_OK;
+}
+
 int rt_sync(rt_ctx* c)
 {
     if (!c) return RT_E_ARG;

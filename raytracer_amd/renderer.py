@@ -177,7 +177,7 @@ class Renderer:
         self.m_settings = Settings()
         self.m_Image = None
         self.m_frameindex = 1
-        self._mesh_key = None
+        self._mesh_ref = None           # the tree object whose mesh is resident (held, so its identity stays unique)
         self.download = True            # Render() ends in Image::SetData (host copy) unless switched off
 
     def __del__(self):
@@ -218,11 +218,11 @@ class Renderer:
         check(h, L.rt_set_materials(h, ptr(mats), len(mats)), "rt_set_materials")
         sph = np.ascontiguousarray(scene.spheres, SPHERE_DTYPE)
         check(h, L.rt_set_spheres(h, ptr(sph), len(sph)), "rt_set_spheres")
-        if scene.kd_tree is not None and self._mesh_key != id(scene.kd_tree):       # mesh + tree go up once
+        if scene.kd_tree is not None and self._mesh_ref is not scene.kd_tree:       # mesh + tree go up once
             check(h, L.rt_set_mesh(h, ptr(scene.verts), len(scene.verts), ptr(scene.tri_idx), ptr(scene.normals9),
                                    ptr(scene.tri_mat), len(scene.tri_idx)), "rt_set_mesh")
             check(h, L.rt_set_kdtree(h, C.byref(scene.kd_tree.flat)), "rt_set_kdtree")
-            self._mesh_key = id(scene.kd_tree)
+            self._mesh_ref = scene.kd_tree
         check(h, L.rt_set_camera(h, ptr(camera.GetPosition()), ptr(camera.GetInverseProjection()),
                                  ptr(camera.GetInverseView())), "rt_set_camera")
 
@@ -231,6 +231,9 @@ class Renderer:
 
     def resolve(self, frame_index):
         check(self._h, self._L.rt_resolve(self._h, frame_index), "rt_resolve")
+
+    def reset_accum(self):
+        check(self._h, self._L.rt_reset_accum(self._h), "rt_reset_accum")
 
     def sync(self):
         check(self._h, self._L.rt_sync(self._h), "rt_sync")

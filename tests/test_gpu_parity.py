@@ -1,0 +1,368 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against the CPU oracle on the same
+scenes, camera, settings and per-(pixel, frame) random streams.
+
+Bar: primary-hit ids bit-exact, accumulated radiance bit-exact (so also within the stated tolerance
+|d| <= 1e-5 + 1e-5*|ref|), the tone-mapped RGBA32F frame bit-exact, ray/node/triangle counters equal.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, bits
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import raytracer_amd
+    return raytracer_amd
+
+
+@pytest.fixture(scope="module")
+def renderer(rt):
+    return rt.Renderer(0)
+
+
+def make_scene(rt, orc, mesh=None, spheres=True, mats_extra=None):
+    """Product scene + oracle scene holding the same data (the oracle takes the product's flat tree: the two builders
+    are proven equal by the CPU tests)."""
+    from raytracer_amd import scenes
+    scene = rt.Scene()
+    mats = scenes.default_materials()
+    if spheres:
+        scene.spheres = scenes.default_spheres()
+    osc = orc.Scene()
+    if mesh is not None:
+        verts, tris, normals9, tri_mat, mesh_mats = mesh
+        tri_mat = (np.asarray(tri_mat, np.uint32) + np.uint32(len(mats))).astype(np.uint32)
+        mats = np.concatenate([mats, mesh_mats])
+        scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=4)
+        osc.set_mesh(verts, tris, normals9, tri_mat)
+        osc.import_kd(scene.kd_tree.arrays())
+    if mats_extra is not None:
+        mats = np.concatenate([mats, mats_extra])
+    scene.materials = mats
+    osc.set_spheres(scene.spheres); osc.set_materials(scene.materials)
+    return scene, osc
+
+
+def run_both(rt, orc, r, scene, osc, w, h, mode, bounces, frames, use_ace=True, aa=False, seed=1337, stats=False,
+             cam=None, threads=8):
+    if cam is None:
+        cam = rt.Camera(70.0, 0.05, 100.0)
+    cam.OnResize(w, h)
+    st = r.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, bounces, use_ace, aa, True, seed
+    r.OnResize(w, h)
+    r.ResetFrameIndex()
+    r.record_ids(True)
+    r.set_stats(stats)
+    r.reset_counters()
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
+    ost = orc.Settings(1, mode, int(use_ace), int(aa), bounces)
+    cnt = orc.Counters()
+    for f in range(1, frames + 1):
+        r.Render(scene, cam)
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, seed=seed, primary_ids=ids if f == 1 else None,
+                         counters=cnt, nthreads=threads)
+    got = dict(ids=r.read_primary_ids().ravel(), acc=r.read_accum().reshape(-1, 3), img=r.GetImage().data.reshape(-1, 4),
+               cnt=r.read_counters())
+    want = dict(ids=ids, acc=acc, img=img, cnt=cnt)
+    r.set_stats(False)
+    return got, want
+
+
+def assert_exact(got, want, counters=("rays",)):
+    assert np.array_equal(got["ids"], want["ids"]), "primary ids: %d pixels differ" % int((got["ids"] != want["ids"]).sum())
+    assert np.array_equal(bits(got["acc"]), bits(want["acc"])), "accumulation: %d values differ, max |d| %g" % (
+        int((bits(got["acc"]) != bits(want["acc"])).sum()), float(np.nanmax(np.abs(got["acc"] - want["acc"]))))
+    # the stated tolerance (trivially met when bit-exact; kept so the bar is written down)
+    assert np.all(np.abs(got["acc"] - want["acc"]) <= 1e-5 + 1e-5 * np.abs(want["acc"]))
+    assert np.array_equal(bits(got["img"]), bits(want["img"])), "image differs"
+    for k in counters:
+        assert getattr(got["cnt"], k) == getattr(want["cnt"], k), (k, getattr(got["cnt"], k), getattr(want["cnt"], k))
+
+
+# ---- spheres --------------------------------------------------------------------------------------------------------------
+def test_default_sphere_scene_bit_exact(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 320, 180, 1, 5, 4)
+    assert_exact(got, want, ("rays", "sphere_tests"))
+    assert (want["ids"] >= 0).all() and len(np.unique(want["ids"])) >= 8       # the closed box: every pixel hits, most spheres seen
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (17, 13), (16, 16), (333, 7), (8, 250)])
+def test_ragged_frame_sizes(rt, orc, renderer, w, h):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 1, 5, 2)
+    assert_exact(got, want)
+
+
+@pytest.mark.parametrize("bounces", [0, 1, 2, 9])
+def test_bounce_counts(rt, orc, renderer, bounces):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 96, 64, 1, bounces, 2)
+    assert_exact(got, want)
+    if bounces == 0:
+        assert got["cnt"].rays == 0 and not got["acc"].any()
+
+
+def test_no_tonemap_and_other_seed(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 128, 72, 1, 5, 3, use_ace=False, seed=99)
+    assert_exact(got, want)
+    got2, _ = run_both(rt, orc, renderer, scene, osc, 128, 72, 1, 5, 3, use_ace=False, seed=1337)
+    assert not np.array_equal(bits(got["acc"]), bits(got2["acc"]))             # the seed reaches the streams
+
+
+def test_anti_aliasing_filter(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 150, 70, 1, 5, 3, aa=True)
+    assert_exact(got, want)
+
+
+def test_refraction_and_total_internal_reflection(rt, orc, renderer):
+    """Glass spheres with a high index: exercises always-transmit, the inside/outside branches and the TIR fall-through."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc)
+    scene.materials = scene.materials.copy()
+    scene.materials[3] = scenes.make_material((0.9, 0.9, 1.0), roughness=0.2, transparency=1.0, ior=1.9)
+    scene.materials[6] = scenes.make_material((1.0, 0.9, 0.9), roughness=0.0, transparency=0.5, ior=2.4)
+    osc.set_materials(scene.materials)
+    got, want = run_both(rt, orc, renderer, scene, osc, 200, 120, 1, 8, 3)
+    assert_exact(got, want)
+
+
+def test_device_ray_generation_bit_exact(rt, orc, renderer):
+    g = np.load(os.path.join(GOLD, "ref_kat.npz"))
+    scene, _ = make_scene(rt, orc)
+    for (w, h) in [(64, 36), (320, 180), (1920, 1080)]:
+        cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+        renderer.OnResize(w, h)
+        renderer.upload(scene, cam)
+        d = renderer.read_ray_dirs()
+        assert orc.fnv1a(d) == int(g["cam_%dx%d_dirs_fnv" % (w, h)][0])        # the reference Camera's own directions
+        if w == 64:
+            assert np.array_equal(bits(d), bits(g["cam_64x36_dirs"]))
+    assert np.all(d.reshape(1080, 1920, 3)[:, 960, 0] == 0.0)
+
+
+def test_host_supplied_ray_directions(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    w, h = 120, 80
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 1, 5, 2)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    renderer.set_ray_dirs(orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h))
+    try:
+        renderer.ResetFrameIndex()
+        for _ in range(2):
+            renderer.Render(scene, cam)
+        assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(want["acc"]))
+    finally:
+        renderer.set_ray_dirs(None)
+
+
+# ---- mesh through the KD tree ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["grid40", "cubesphere16"])
+def test_mesh_bit_exact_with_counters(rt, orc, renderer, name):
+    from raytracer_amd import scenes
+    mesh = scenes.displaced_grid(40) if name == "grid40" else scenes.cube_sphere(16)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    got, want = run_both(rt, orc, renderer, scene, osc, 160, 90, 0, 8, 3, stats=True)
+    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested"))
+    assert (want["ids"] >= 0).sum() > 500 and (want["ids"] < 0).sum() > 500
+
+
+def test_mesh_centred_on_zero_direction_column(rt, orc, renderer):
+    """The centre pixel column has direction.x == 0 (1/0 = inf) and the grid is centred on x = 0, so (center.x - origin.x)
+    * inf = NaN in the slab test: the reference counts such boxes as hit and never prunes them."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(32))
+    got, want = run_both(rt, orc, renderer, scene, osc, 64, 48, 0, 4, 2, stats=True)
+    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested"))
+    col = want["ids"].reshape(48, 64)[:, 32]
+    assert (col >= 0).any()
+
+
+def test_reference_built_tree_and_reference_hits(rt, orc, renderer):
+    """Upload the tree the REFERENCE's KDTreeCPU built (golden fixture) and compare the primary ids with the ids the
+    reference's own KDTreeCPU::intersect returned."""
+    from raytracer_amd import scenes
+    g = np.load(os.path.join(GOLD, "ref_kd_grid40.npz"))
+    verts, tris, normals9, tri_mat, mesh_mats = scenes.displaced_grid(40)
+    scene = rt.Scene()
+    scene.materials = mesh_mats
+    scene.set_triangles(verts, tris, normals9, tri_mat, build_kd=False)
+    scene.kd_tree = rt.FlatKDTree(g["center"], g["extent"], g["left"], g["right"], g["first"], g["count"], g["leaf_idx"])
+    w, h = (int(x) for x in g["width"])
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.AntiAliasing = 0, 1, False
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
+    renderer.Render(scene, cam)
+    assert np.array_equal(renderer.read_primary_ids().ravel(), g["primary_ids"])
+
+
+def test_spheres_and_mesh_together(rt, orc, renderer):
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.cube_sphere(12, center=(0.2, 0.7, -0.6), radius=0.5))
+    got, want = run_both(rt, orc, renderer, scene, osc, 192, 108, 2, 6, 3, stats=True)
+    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested", "sphere_tests"))
+    tri = (want["ids"] >= 0x40000000).sum(); sph = ((want["ids"] >= 0) & (want["ids"] < 0x40000000)).sum()
+    assert tri > 300 and sph > 300
+
+
+# ---- Renderer semantics ----------------------------------------------------------------------------------------------------
+def test_frames_in_one_launch_equal_separate_launches(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 160, 96, 1, 5, 6)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(160, 96)
+    renderer.ResetFrameIndex()
+    renderer.Render(scene, cam, frames=4)
+    renderer.Render(scene, cam, frames=2)
+    assert renderer.GetFrameIndex() == 7
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(want["acc"]))
+    assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(want["img"]))
+
+
+def test_accumulate_off_and_reset(rt, orc, renderer):
+    scene, osc = make_scene(rt, orc)
+    w, h = 100, 60
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.Accumulate, st.AntiAliasing, st.UseACE_Color = 1, 5, False, False, True
+    renderer.OnResize(w, h); renderer.ResetFrameIndex()
+    renderer.Render(scene, cam); a1 = renderer.read_accum().copy()
+    renderer.Render(scene, cam); a2 = renderer.read_accum().copy()
+    assert renderer.GetFrameIndex() == 1 and np.array_equal(bits(a1), bits(a2))      # frame 1 re-rendered, not summed
+    st.Accumulate = True
+    renderer.Render(scene, cam); renderer.Render(scene, cam)
+    assert renderer.GetFrameIndex() == 3
+    renderer.ResetFrameIndex()                                                       # what a camera move does
+    renderer.Render(scene, cam)
+    assert np.array_equal(bits(renderer.read_accum()), bits(a1))
+    renderer.OnResize(w, h)                                                          # unchanged size: no reset
+    assert renderer.GetFrameIndex() == 2
+
+
+def test_live_edits_between_frames_keep_accumulating(rt, orc, renderer):
+    """The UI edits spheres/materials between frames without resetting accumulation (RaytracerApp.cpp:283-331)."""
+    scene, osc = make_scene(rt, orc)
+    w, h = 120, 72
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.Accumulate, st.AntiAliasing, st.UseACE_Color, st.Seed = 1, 5, True, False, True, 1337
+    renderer.OnResize(w, h); renderer.ResetFrameIndex()
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    ost = orc.Settings(1, 1, 1, 0, 5)
+    for f in range(1, 4):
+        if f == 2:
+            scene.spheres = scene.spheres.copy(); scene.spheres[5]["y"] = 0.6; scene.spheres[7]["radius"] = 0.35
+            scene.materials = scene.materials.copy(); scene.materials[1]["albedo"] = (0.1, 0.2, 0.9)
+            osc.set_spheres(scene.spheres); osc.set_materials(scene.materials)
+        renderer.Render(scene, cam)
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img)
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(acc))
+
+
+def test_errors_are_reported_not_faulted(rt, orc, renderer):
+    from raytracer_amd import _capi
+    r2 = rt.Renderer(0)
+    scene, _ = make_scene(rt, orc)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(32, 32)
+    with pytest.raises(_capi.RtError):
+        r2.render_only(1)                                            # before OnResize
+    r2.OnResize(32, 32)
+    with pytest.raises(_capi.RtError):
+        r2.render_only(1)                                            # before a camera
+    r2.GetSettings().SceneMode = 0
+    with pytest.raises(_capi.RtError):
+        r2.Render(scene, cam)                                        # mesh mode without a tree
+    r2.GetSettings().SceneMode = 1
+    bad = rt.Scene(); bad.spheres = scene.spheres.copy(); bad.spheres[2]["material"] = 700; bad.materials = scene.materials
+    with pytest.raises(_capi.RtError):
+        r2.Render(bad, cam)                                          # material index out of range
+    with pytest.raises(_capi.RtError):
+        r2.render_only(0)                                            # frame indices are 1-based
+    r2.Render(scene, cam)                                            # and the context still works afterwards
+
+
+# ---- partitions for several GPUs, exercised on one ----------------------------------------------------------------------
+def test_tile_split_bands_assemble_the_frame(rt, orc, renderer):
+    from raytracer_amd import dist as rtd
+    scene, osc = make_scene(rt, orc)
+    w, h = 200, 150
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 1, 5, 2)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    world = 3
+    out = np.zeros((h, w, 3), np.float32)
+    for rank in range(world):
+        rr = rt.Renderer(0)
+        s = rr.GetSettings(); s.SceneMode, s.Bounces = 1, 5
+        rr.OnResize(w, h); rr.set_bands(rank, world)
+        rr.Render(scene, cam); rr.Render(scene, cam)
+        rows = rtd.band_rows(h, rank, world)
+        out[rows] = rr.read_accum()[rows]
+    assert np.array_equal(bits(out.reshape(-1, 3)), bits(want["acc"]))
+
+
+def test_sample_split_sum_matches_within_reassociation_tolerance(rt, orc, renderer):
+    from raytracer_amd import dist as rtd
+    scene, osc = make_scene(rt, orc)
+    w, h, world, per = 160, 100, 4, 3
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 1, 5, world * per)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    total = np.zeros((h, w, 3), np.float32)
+    for rank in range(world):
+        rr = rt.Renderer(0)
+        s = rr.GetSettings(); s.SceneMode, s.Bounces = 1, 5
+        rr.OnResize(w, h); rr.upload(scene, cam); rr.reset_accum()
+        for f in rtd.frames_for_rank(rank, world, per):
+            rr.render_only(f)
+        total += rr.read_accum()
+    ref = want["acc"].reshape(h, w, 3)
+    assert np.all(np.abs(total - ref) <= 1e-4 + 1e-4 * np.abs(ref))
+
+
+# ---- full-size configurations ------------------------------------------------------------------------------------------------
+def test_config2_1080p_sphere_scene_ids_and_accumulation(rt, orc, renderer):
+    """BASELINE configs[1] at full size: all 2,073,600 primary ids and two frames of accumulation, bit-exact."""
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 1920, 1080, 1, 5, 2, threads=16)
+    assert_exact(got, want)
+    # 64 frames: deterministic run to run, finite, and every pixel received light at least once
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(1920, 1080)
+    sums = []
+    for _ in range(2):
+        renderer.ResetFrameIndex()
+        renderer.download = False
+        renderer.Render(scene, cam, frames=1)
+        for _f in range(63):
+            renderer.Render(scene, cam)
+        renderer.download = True
+        sums.append(renderer.read_accum())
+    assert np.array_equal(bits(sums[0]), bits(sums[1]))
+    assert np.isfinite(sums[0]).all() and (sums[0].sum(axis=2) > 0).mean() > 0.99
+
+
+def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
+    """BASELINE configs[2] at full size: primary ids of all 1080p pixels through the 69,938-triangle tree, bit-exact;
+    then one 8-bounce frame at a sixteenth of the rows against the oracle."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(187), spheres=False)
+    w, h = 1920, 1080
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.AntiAliasing, st.Accumulate, st.UseACE_Color, st.Seed = 0, 8, False, True, True, 1337
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
+    renderer.Render(scene, cam)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    ids, *_ = osc.trace_primary(0, cam.GetPosition(), dirs)
+    got_ids = renderer.read_primary_ids().ravel()
+    assert np.array_equal(got_ids, ids)
+    assert (ids >= 0).sum() > 100000
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    osc.render_frame(orc.Settings(1, 0, 1, 0, 8), cam.GetPosition(), dirs, w, h, 1, acc, img, nthreads=16, row_step=16)
+    rows = np.arange(0, h, 16)
+    assert np.array_equal(bits(renderer.read_accum()[rows]), bits(acc.reshape(h, w, 3)[rows]))
