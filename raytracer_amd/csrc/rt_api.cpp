@@ -14,7 +14,9 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
 
-extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned gx, unsigned gy, hipStream_t s);
+extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned grid, hipStream_t s);
+extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int* blocks_per_cu);
+extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 
@@ -62,12 +64,16 @@ struct rt_ctx {
     std::vector<uint32_t> h_tris;
     std::vector<uint32_t> h_sphere_mat, h_tri_mat;
 
-    DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image;
+    DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image, d_dirs;
     DevBuf<uint32_t> d_sphere_mat;
-    DevBuf<float> d_ray_dirs, d_out_dirs;
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters;
-    bool use_host_dirs = false;
+    std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
+    bool use_host_dirs = false;          // d_dirs holds directions the host supplied (rt_set_ray_dirs)
+    bool dirs_dirty = true;              // d_dirs must be regenerated from the camera before the next trace
+
+    int n_cus = 0;
+    int blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};   // trace-kernel residency per (mode, stats), queried once
 
     rt_kernel_time ktime{0, 0.0, 0.0};
 };
@@ -92,12 +98,15 @@ struct DeviceGuard {
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+// 16x16-pixel workgroups over the bands this context owns (resolve / AA kernels); gy = number of owned bands.
 void grid_for(const rt_ctx* c, unsigned& gx, unsigned& gy)
 {
     gx = (c->width + RT_TILE - 1) / RT_TILE;
     unsigned bands = (c->height + RT_TILE - 1) / RT_TILE;
     gy = bands > c->band_index ? (bands - c->band_index + c->band_count - 1) / c->band_count : 0;
 }
+
+constexpr unsigned kMaxBlocksPerCu = 8;      // 8 workgroups of 4 waves = the 32 waves a CU can hold
 
 void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames)
 {
@@ -110,13 +119,16 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.seed = c->settings.seed; p.bounces = c->settings.bounces;
     p.n_spheres = c->n_spheres; p.n_materials = c->n_materials; p.n_nodes = c->n_nodes;
     p.band_index = c->band_index; p.band_count = c->band_count;
+    unsigned gx, gy; grid_for(c, gx, gy);
+    p.tile_rows = 2u * gy;                               // two 8-row tile rows per 16-row band
+    p.n_units = ((c->width + 7) / 8) * p.tile_rows * (64u / RT_UNIT);
+    for (uint32_t i = 0; i < c->n_spheres && i < RT_INLINE_SPHERES; ++i) p.sph_inline[i] = c->h_spheres[i];
     p.use_ace = c->settings.use_ace;
     p.spheres = c->d_spheres.ptr; p.sphere_mat = c->d_sphere_mat.ptr; p.materials = c->d_materials.ptr;
     p.nodes = c->d_nodes.ptr; p.leafrecs = c->d_leafrecs.ptr; p.trishade = c->d_trishade.ptr;
-    p.ray_dirs = c->use_host_dirs ? c->d_ray_dirs.ptr : nullptr;
+    p.dirs = c->d_dirs.ptr; p.dirs_out = c->d_dirs.ptr;
     p.accum = c->d_accum.ptr; p.image = c->d_image.ptr;
     p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
-    p.out_dirs = nullptr;
     p.counters = c->d_counters.ptr;
 }
 
@@ -174,6 +186,14 @@ rt_ctx* rt_create(int device_id)
         rt_destroy(c); return nullptr;
     }
     c->stream = c->own_stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || prop.multiProcessorCount <= 0 ||
+        c->d_counters.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * 4) != hipSuccess ||
+        hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess) {
+        fail(nullptr, RT_E_HIP, "device query / counter allocation failed on device %d", device_id);
+        rt_destroy(c); return nullptr;
+    }
+    c->n_cus = prop.multiProcessorCount;
     return c;
 }
 
@@ -184,7 +204,7 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_spheres.release(); c->d_materials.release(); c->d_nodes.release(); c->d_leafrecs.release();
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
-    c->d_ray_dirs.release(); c->d_out_dirs.release(); c->d_ids.release(); c->d_counters.release();
+    c->d_dirs.release(); c->d_ids.release(); c->d_counters.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -215,14 +235,11 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
     HIP_TRY(c, c->d_accum.resize(n));
     HIP_TRY(c, c->d_image.resize(n));
     HIP_TRY(c, c->d_ids.resize(n));
-    const size_t groups = (size_t)((w + RT_TILE - 1) / RT_TILE) * ((h + RT_TILE - 1) / RT_TILE);
-    HIP_TRY(c, c->d_counters.resize(groups * 4));
+    HIP_TRY(c, c->d_dirs.resize(n));
     HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, n * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_image.ptr, 0, n * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_ids.ptr, 0xFF, n * sizeof(int32_t), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, groups * 4 * sizeof(unsigned long long), c->stream));
-    c->d_ray_dirs.release(); c->use_host_dirs = false;
-    c->d_out_dirs.release();
+    c->use_host_dirs = false; c->dirs_dirty = true;
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -239,7 +256,8 @@ int rt_set_spheres(rt_ctx* c, const rt_sphere* sp, uint32_t n)
 {
     if (!c || (n && !sp)) return RT_E_ARG;
     DeviceGuard g(c->device);
-    std::vector<float4> packed(n);
+    std::vector<float4>& packed = c->h_spheres;
+    packed.resize(n);
     c->h_sphere_mat.resize(n);
     for (uint32_t i = 0; i < n; ++i) {
         packed[i] = make_float4(sp[i].x, sp[i].y, sp[i].z, sp[i].radius * sp[i].radius);   // Renderer.cpp:257's r*r
@@ -383,6 +401,8 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
 int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const float inv_view[16])
 {
     if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
+    // directions are regenerated only when the matrices change (Camera.cpp:96-100,113-114)
+    if (!c->have_camera || memcmp(c->inv_proj, inv_proj, 64) != 0 || memcmp(c->inv_view, inv_view, 64) != 0) c->dirs_dirty = true;
     memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
     c->have_camera = true;
     return RT_OK;
@@ -392,12 +412,13 @@ int rt_set_ray_dirs(rt_ctx* c, const float* xyz, size_t n)
 {
     if (!c) return RT_E_ARG;
     DeviceGuard g(c->device);
-    if (!xyz) { c->use_host_dirs = false; return RT_OK; }
+    if (!xyz) { if (c->use_host_dirs) { c->use_host_dirs = false; c->dirs_dirty = true; } return RT_OK; }
     if (!c->width || n != (size_t)c->width * c->height) return fail(c, RT_E_ARG, "rt_set_ray_dirs: %zu directions for a %ux%u frame", n, c->width, c->height);
+    std::vector<float4> packed(n);
+    for (size_t i = 0; i < n; ++i) packed[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_ray_dirs.resize(3 * n));
-    HIP_TRY(c, hipMemcpy(c->d_ray_dirs.ptr, xyz, 3 * n * sizeof(float), hipMemcpyHostToDevice));
-    c->use_host_dirs = true;
+    HIP_TRY(c, hipMemcpy(c->d_dirs.ptr, packed.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    c->use_host_dirs = true; c->dirs_dirty = false;
     return RT_OK;
 }
 
@@ -408,13 +429,41 @@ int rt_set_bands(rt_ctx* c, uint32_t band_index, uint32_t band_count)
     return RT_OK;
 }
 
+namespace {
+
+// Camera ray directions into d_dirs when the camera or the frame size changed since they were last generated.
+int ensure_dirs(rt_ctx* c, const RtParams& p)
+{
+    if (!c->dirs_dirty || c->use_host_dirs) return RT_OK;
+    HIP_TRY(c, rt_launch_raygen(&p, c->stream));
+    c->dirs_dirty = false;
+    return RT_OK;
+}
+
+// Workgroups of the persistent trace grid: what the chip holds at once, but no more than there are tiles to hand out.
+int trace_grid(rt_ctx* c, int mode, bool stats, uint32_t n_units, unsigned& grid)
+{
+    int& per_cu = c->blocks_per_cu[mode * 2 + (stats ? 1 : 0)];
+    if (per_cu == 0) {
+        int q = 0;
+        HIP_TRY(c, rt_trace_occupancy(mode, stats ? 1 : 0, &q));
+        per_cu = q < 1 ? 1 : (q > (int)kMaxBlocksPerCu ? (int)kMaxBlocksPerCu : q);
+    }
+    grid = (unsigned)c->n_cus * (unsigned)per_cu;
+    const unsigned by_work = (n_units * RT_UNIT / 64u + 3) / 4;      // a wave per 64 pixels is the most that can help
+    if (grid > by_work) grid = by_work;
+    if (grid == 0) grid = 1;
+    return RT_OK;
+}
+
+}  // namespace
+
 int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
 {
     if (!c) return RT_E_ARG;
     if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
     if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
-    if (!c->have_camera && !c->use_host_dirs) return fail(c, RT_E_STATE, "rt_render before rt_set_camera / rt_set_ray_dirs");
-    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render needs the camera position (rt_set_camera)");
+    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render before rt_set_camera (the camera position is needed even with rt_set_ray_dirs)");
     const int mode = c->settings.scene_mode;
     if (int rc = validate_scene(c, mode)) return rc;
     DeviceGuard g(c->device);
@@ -423,11 +472,15 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     RtParams p; fill_params(c, p, frame_index, n);
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
+    if (int rc = ensure_dirs(c, p)) return rc;
+    unsigned grid;
+    if (int rc = trace_grid(c, mode, c->stats, p.n_units, grid)) return rc;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
-    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, gx, gy, c->stream));
+    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
+    HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));
     if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index + n - 1, gx, gy, c->stream));
     return RT_OK;
 }
@@ -500,27 +553,15 @@ int rt_read_primary_ids(rt_ctx* c, int32_t* out)
 int rt_read_ray_dirs(rt_ctx* c, float* out_xyz)
 {
     if (!c || !out_xyz) return RT_E_ARG;
-    if (!c->width || !c->have_camera) return fail(c, RT_E_STATE, "rt_read_ray_dirs before rt_resize/rt_set_camera");
+    if (!c->width || (!c->have_camera && !c->use_host_dirs)) return fail(c, RT_E_STATE, "rt_read_ray_dirs before rt_resize/rt_set_camera");
     DeviceGuard g(c->device);
     const size_t n = (size_t)c->width * c->height;
-    HIP_TRY(c, c->d_out_dirs.resize(3 * n));
-    // a zero-bounce launch generates (or passes through) the directions and touches nothing else of value:
-    // accumulation and image are saved and restored around it.
-    RtParams p; fill_params(c, p, 2, 1);
-    p.bounces = 0; p.out_dirs = c->d_out_dirs.ptr; p.primary_ids = nullptr; p.counters = nullptr;
-    DevBuf<float4> scratch_accum, scratch_image;
-    HIP_TRY(c, scratch_accum.resize(n));
-    HIP_TRY(c, scratch_image.resize(n));
-    p.accum = scratch_accum.ptr; p.image = scratch_image.ptr;
-    HIP_TRY(c, hipMemsetAsync(scratch_accum.ptr, 0, n * sizeof(float4), c->stream));
-    unsigned gx, gy; grid_for(c, gx, gy);
-    p.band_index = 0; p.band_count = 1;                 // directions for the whole frame, whatever bands we own
-    gy = (c->height + RT_TILE - 1) / RT_TILE;
-    hipError_t e = rt_launch_trace(&p, RT_MODE_SPHERES, 0, gx, gy, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out_xyz, c->d_out_dirs.ptr, 3 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    scratch_accum.release(); scratch_image.release();
-    if (e != hipSuccess) return fail(c, RT_E_HIP, "rt_read_ray_dirs: %s", hipGetErrorString(e));
+    RtParams p; fill_params(c, p, 1, 1);
+    if (int rc = ensure_dirs(c, p)) return rc;
+    std::vector<float4> tmp(n);
+    HIP_TRY(c, hipMemcpyAsync(tmp.data(), c->d_dirs.ptr, n * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    if (int rc = rt_sync(c)) return rc;
+    for (size_t i = 0; i < n; ++i) { out_xyz[3 * i] = tmp[i].x; out_xyz[3 * i + 1] = tmp[i].y; out_xyz[3 * i + 2] = tmp[i].z; }
     return RT_OK;
 }
 

@@ -9,6 +9,9 @@
 #define RT_MODE_SPHERES 1
 #define RT_MODE_BOTH    2
 
+#define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile; units are dealt to waves round-robin
+#define RT_INLINE_SPHERES 32       // spheres carried in the kernel arguments (scalar loads); more go through HBM
+
 #define RT_LEAF_INTERIOR (-1)      // RtNode.leaf_first: not a leaf
 #define RT_LEAF_EMPTY    (-2)      // a leaf that owns no triangle
 
@@ -28,6 +31,7 @@
 //               [0] = { n0.x, n0.y, n0.z, n1.x }  [1] = { n1.y, n1.z, n2.x, n2.y }  [2] = { n2.z, bits(material), 0, 0 }
 //  spheres  : float4 { center.xyz, radius*radius } + uint32 material, index order = Scene::spheres order
 //  materials: 3 x float4 { albedo.rgb, roughness } { emission.rgb, transparency } { ior, 0, 0, 0 }
+//  dirs     : float4 per pixel { direction.xyz, 0 }: Camera::m_RayDirections (Camera.h:43), kept until the camera moves
 //  accum    : float4 per pixel { r, g, b, unused }, row-major, row 0 first (m_AccumulationBuffer, Renderer.h:157)
 //  image    : float4 per pixel RGBA32F (m_ImageData, Renderer.h:156)
 
@@ -40,7 +44,8 @@ struct RtParams {
     uint32_t seed, bounces;
     uint32_t n_spheres, n_materials;
     uint32_t n_nodes;
-    uint32_t band_index, band_count;       // screen-tile split: this launch covers bands b*band_count + band_index
+    uint32_t band_index, band_count;       // screen-tile split: this context renders bands b*band_count + band_index
+    uint32_t tile_rows, n_units;           // 8-row tile rows / RT_UNIT-pixel work units in the bands this context renders
     int32_t  use_ace;
     const float4* spheres;
     const uint32_t* sphere_mat;
@@ -48,10 +53,11 @@ struct RtParams {
     const float4* nodes;
     const float4* leafrecs;
     const float4* trishade;
-    const float*  ray_dirs;                 // optional host-supplied directions (xyz per pixel), else nullptr
+    const float4* dirs;                     // ray direction per pixel { x, y, z, 0 } (generated on the device or uploaded)
+    float4* dirs_out;                       // raygen kernel's output (same buffer)
     float4* accum;
     float4* image;
     int32_t* primary_ids;                   // optional
-    float*   out_dirs;                      // optional: generated directions (verification)
-    unsigned long long* counters;           // 4 per workgroup: rays, nodes, tris, sphere tests
+    unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
+    float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

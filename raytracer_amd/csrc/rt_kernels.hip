@@ -190,25 +190,75 @@ __device__ __forceinline__ F3 camera_dir(const RtParams& p, uint32_t x, uint32_t
 struct Hit { float t; int32_t id; float u, v; };
 
 // ---- spheres: Renderer.cpp:243-271 ------------------------------------------------------------------------------
-__device__ __forceinline__ void trace_spheres(const RtParams& p, F3 O, F3 D, float& closest, int& index)
+// The reference computes t = (-b - sqrt(disc)) / (2a) for every sphere with disc >= 0 and keeps the first strictly smaller
+// positive t.  Two exact shortcuts skip work whose outcome is already decided:
+//   * b >= 0  =>  the numerator -b - sqrt(disc) <= 0  =>  t <= 0: rejected by "t > 0";
+//   * all candidates share the positive divisor 2a and IEEE division is monotone in the numerator, so a numerator that is
+//     not below the best numerator so far cannot give a strictly smaller t: rejected by "t < closest".
+// Both leave closest / index exactly as the reference's loop would.
+template <bool INLINE>
+__device__ __forceinline__ void trace_spheres_from(const RtParams& p, F3 O, F3 D, float& closest, int& index)
 {
     float a = dot3(D, D);
     float dbl_a = 2.0f * a;
     float four_a = 4.0f * a;
-    for (uint32_t i = 0; i < p.n_spheres; ++i) {
-        float4 sp = p.spheres[i];                      // wave-uniform address: scalar load
-        F3 ro = O - f3(sp.x, sp.y, sp.z);
+    float best_num = __builtin_inff();
+    const uint32_t n = p.n_spheres;
+    for (uint32_t i = 0; i < n; ++i) {
+        const float4 cur = INLINE ? p.sph_inline[i] : p.spheres[i];     // wave-uniform index
+        F3 ro = O - f3(cur.x, cur.y, cur.z);
         float b = 2.0f * dot3(ro, D);
-        float c = dot3(ro, ro) - sp.w;                 // sp.w = radius*radius, rounded once at upload
+        float c = dot3(ro, ro) - cur.w;                    // cur.w = radius*radius, rounded once at upload
         float disc = b * b - four_a * c;
-        if (disc >= 0.0f) {
-            float t = (-b - sqrtf(disc)) / dbl_a;
-            if (t > 0.0f && t < closest) { closest = t; index = (int)i; }
+        if (disc >= 0.0f && b < 0.0f) {
+            float num = -b - sqrtf(disc);
+            if (num > 0.0f && num < best_num) {
+                float t = num / dbl_a;
+                if (t > 0.0f && t < closest) { closest = t; index = (int)i; best_num = num; }
+            }
         }
     }
 }
 
+__device__ __forceinline__ void trace_spheres(const RtParams& p, F3 O, F3 D, float& closest, int& index)
+{
+    if (p.n_spheres <= RT_INLINE_SPHERES) trace_spheres_from<true>(p, O, D, closest, index);   // kernel-argument copy
+    else trace_spheres_from<false>(p, O, D, closest, index);
+}
+
 // ---- KD tree: KDTreeCPU.cpp:640-708 over the preorder/skip layout; Intersections.cpp:23-94 ------------------------
+// Intersections::aabbIntersect (Intersections.cpp:23-47) with compare+select min/max in the reference's operand order.
+__device__ __forceinline__ bool slab_test(float4 n0, float4 n1, F3 O, F3 invD, float& tNear)
+{
+    F3 l1 = (f3(n0.x, n0.y, n0.z) - O) * invD;
+    F3 l2 = f3(n1.x, n1.y, n1.z) * invD;
+    F3 tMin = l1 - l2;
+    F3 tMax = l1 + l2;
+    float t2x = sel_max(tMin.x, tMax.x), t2y = sel_max(tMin.y, tMax.y), t2z = sel_max(tMin.z, tMax.z);
+    float tFar = sel_min(sel_min(t2x, t2y), t2z);
+    float t1x = sel_min(tMin.x, tMax.x), t1y = sel_min(tMin.y, tMax.y), t1z = sel_min(tMin.z, tMax.z);
+    tNear = sel_max(sel_max(t1x, t1y), t1z);
+    return !(tFar < 0.0f) && !(tNear > tFar);
+}
+
+// Intersections::triIntersect (Intersections.cpp:56-94) on a pre-gathered record (e1, e2 formed at upload).
+__device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, F3 D, float& tt, float& u, float& v)
+{
+    F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+    F3 h = cross3(D, e2);
+    float a = dot3(e1, h);
+    bool ok = !(a > -0.00001f && a < 0.00001f);
+    float f = 1.0f / a;
+    F3 s = O - v0;
+    u = f * dot3(s, h);
+    ok = ok && !(u < 0.0f || u > 1.0f);
+    F3 q = cross3(s, e1);
+    v = f * dot3(D, q);
+    ok = ok && !(v < 0.0f || u + v > 1.0f);
+    tt = f * dot3(e2, q);
+    return ok && (tt > 0.00001f);
+}
+
 template <bool STATS>
 __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 invD, Hit& hit, uint32_t& n_nodes_visited,
                                            uint32_t& n_tris_tested)
@@ -222,18 +272,10 @@ __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 inv
         const float4 n0 = p.nodes[2 * node];
         const float4 n1 = p.nodes[2 * node + 1];
         if (STATS) n_nodes_visited++;
-        // aabbIntersect
-        F3 l1 = (f3(n0.x, n0.y, n0.z) - O) * invD;
-        F3 l2 = f3(n1.x, n1.y, n1.z) * invD;
-        F3 tMin = l1 - l2;
-        F3 tMax = l1 + l2;
-        float t2x = sel_max(tMin.x, tMax.x), t2y = sel_max(tMin.y, tMax.y), t2z = sel_max(tMin.z, tMax.z);
-        float tFar = sel_min(sel_min(t2x, t2y), t2z);
-        float t1x = sel_min(tMin.x, tMax.x), t1y = sel_min(tMin.y, tMax.y), t1z = sel_min(tMin.z, tMax.z);
-        float tNear = sel_max(sel_max(t1x, t1y), t1z);
-        bool box = !(tFar < 0.0f) && !(tNear > tFar);
+        float tNear;
+        const bool box = slab_test(n0, n1, O, invD, tNear);
         // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
-        bool descend = box && !(tNear > t);
+        const bool descend = box && !(tNear > t);
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
         if (!descend) { node = skip; continue; }
@@ -245,27 +287,86 @@ __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 inv
                 rec += 3;
                 if (STATS) n_tris_tested++;
                 const uint32_t tag = __float_as_uint(r2.y);
-                // triIntersect (e1, e2 precomputed)
-                F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
-                F3 h = cross3(D, e2);
-                float a = dot3(e1, h);
-                bool ok = !(a > -0.00001f && a < 0.00001f);
-                float f = 1.0f / a;
-                F3 s = O - v0;
-                float u = f * dot3(s, h);
-                ok = ok && !(u < 0.0f || u > 1.0f);
-                F3 q = cross3(s, e1);
-                float v = f * dot3(D, q);
-                ok = ok && !(v < 0.0f || u + v > 1.0f);
-                float tt = f * dot3(e2, q);
-                ok = ok && (tt > 0.00001f);
-                if (ok && tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; }
+                float tt, u, v;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; }
                 if (tag & 0x80000000u) break;
             }
         }
         node = skip;
     }
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
+}
+
+// A ray with direction.x == 0 exactly has an infinite inverse there, and the slab test then yields NaN for every box on one
+// side of the origin (inf - inf): such a box counts as hit with t_near = NaN and "NaN > t" never prunes it.  (A zero in y or z
+// does not stick: the reference's select order drops those NaNs and the ray is pruned as usual.)  Every
+// decision of the reference traversal is then independent of the running closest t, so the set of visited leaves is fixed
+// and the result is the smallest t over them, the earliest-visited triangle winning ties.  That lets the whole wave walk
+// the tree for one such ray: each lane takes one node of a 64-node window of the preorder array, a prefix-maximum of the
+// skip links of the rejected nodes tells which nodes of the window are still reachable, reached leaves are tested lane-
+// parallel, and the per-lane winners are merged by (t, record index) -- record indices grow in visit order.
+// Without this a centre-column ray of the default camera (direction.x == 0) walks half the tree alone, ~10^5 dependent steps.
+// Returns false (and no result) if some reached node's decision did depend on t: the caller then walks the tree the serial way.
+template <bool STATS>
+__device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, F3 D, F3 invD, uint32_t lane, Hit& hit,
+                                                       uint32_t& n_nodes_visited, uint32_t& n_tris_tested)
+{
+    float t = FLT_MAX, hu = 0.0f, hv = 0.0f;
+    uint32_t best_rec = 0xFFFFFFFFu;
+    int32_t tri = -1;
+    uint32_t base = 0, killed_to = 0;                       // wave-uniform: window start; nodes below killed_to are unreachable
+    const uint32_t end = p.n_nodes;
+    bool t_dependent = false;
+    while (base < end) {
+        const uint32_t j = base + lane;
+        const bool valid = j < end;
+        float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+        if (valid) { n0 = p.nodes[2 * j]; n1 = p.nodes[2 * j + 1]; }
+        float tNear;
+        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const uint32_t skip = __float_as_uint(n0.w);
+        const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+        uint32_t kill_end = (valid && !box) ? skip : 0u;
+        // exclusive prefix maximum over lower lanes
+        uint32_t pm = kill_end;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(pm, off);
+            if ((int)lane >= off) pm = pm > o ? pm : o;
+        }
+        uint32_t excl = __shfl_up(pm, 1);
+        if (lane == 0) excl = 0u;
+        const uint32_t limit = excl > killed_to ? excl : killed_to;
+        const bool reached = valid && j >= limit;
+        if (reached && box && tNear == tNear) t_dependent = true;        // a finite t_near could be pruned: not our case
+        if (STATS && reached) n_nodes_visited++;
+        if (reached && box && leaf_first >= 0) {
+            uint32_t rec_index = (uint32_t)leaf_first;
+            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
+            for (;;) {
+                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                rec += 3;
+                if (STATS) n_tris_tested++;
+                const uint32_t tag = __float_as_uint(r2.y);
+                float tt, u, v;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; best_rec = rec_index; }
+                ++rec_index;
+                if (tag & 0x80000000u) break;
+            }
+        }
+        const uint32_t window_kill = __shfl(pm, 63);        // maximum over the whole window
+        if (window_kill > killed_to) killed_to = window_kill;
+        base += 64u;
+        if (killed_to > base) base = killed_to;             // everything up to killed_to is inside a rejected subtree
+    }
+    if (__ballot(t_dependent) != 0ull) return false;
+    // merge lane winners: smallest t, then smallest record index (= earliest visit)
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ot = __shfl_xor(t, off); const uint32_t orec = __shfl_xor(best_rec, off);
+        const int32_t otri = __shfl_xor(tri, off); const float ou = __shfl_xor(hu, off), ov = __shfl_xor(hv, off);
+        if (ot < t || (ot == t && orec < best_rec)) { t = ot; best_rec = orec; tri = otri; hu = ou; hv = ov; }
+    }
+    hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
+    return true;
 }
 
 // Util::RandomUnitVector (Renderer.h:46-54)
@@ -282,143 +383,232 @@ __device__ __forceinline__ F3 random_unit_vector(unsigned long long& rng)
 
 constexpr float EPSILON = 0.0002f;         // Renderer.cpp:14
 
-// Renderer::PerPixel (Renderer.cpp:138-229) for one (pixel, frame)
-template <int MODE, bool STATS>
-__device__ __forceinline__ F3 per_pixel(const RtParams& p, F3 O, F3 D, unsigned long long rng, int32_t& primary_id,
-                                        uint32_t& n_rays, uint32_t& n_nodes, uint32_t& n_tris)
+// ---- one lane = one path at a time ---------------------------------------------------------------------------------------
+// Path state of Renderer::PerPixel (Renderer.cpp:138-229) kept across loop iterations so that a lane whose path has ended
+// can start its next pixel while its neighbours are still bouncing.
+struct Path {
+    F3 O, D, contribution, finalColor;
+    unsigned long long rng;
+    uint32_t bounce;
+};
+
+__device__ __forceinline__ void path_begin(Path& s, const RtParams& p, uint32_t pixel, uint32_t frame)
 {
-    F3 finalColor = f3(0.0f, 0.0f, 0.0f);
-    F3 contribution = f3(1.0f, 1.0f, 1.0f);
-    const F3 ambientColor = f3(0.0f, 0.0f, 0.0f);
-    primary_id = -1;
+    const float4 d = p.dirs[pixel];
+    s.O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+    s.D = f3(d.x, d.y, d.z);
+    s.contribution = f3(1.0f, 1.0f, 1.0f);
+    s.finalColor = f3(0.0f, 0.0f, 0.0f);
+    s.rng = pixel_seed(pixel, frame, p.seed);
+    s.bounce = 0;
+}
 
-    for (uint32_t i = 0; i < p.bounces; ++i) {
-        F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-        n_rays++;
+// One iteration of the bounce loop (Renderer.cpp:149-226).  Returns true when the path has ended (miss, roulette, or the
+// bounce budget is used up).
+template <int MODE, bool STATS>
+__device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* primary_id, bool have_mesh_hit, Hit mesh_hit,
+                                          uint32_t& n_rays, uint32_t& n_nodes, uint32_t& n_tris)
+{
+    if (s.bounce >= p.bounces) return true;                // "for (i = 0; i < Bounces; i++)" with Bounces == 0
+    const bool first = s.bounce == 0;
+    s.bounce++;
+    const bool last = s.bounce >= p.bounces;
+    n_rays++;
 
-        // TraceRay (Renderer.cpp:231-301)
-        float tS = FLT_MAX; int iS = -1;
-        Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
-        if (MODE == RT_MODE_SPHERES || MODE == RT_MODE_BOTH) trace_spheres(p, O, D, tS, iS);
-        if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) trace_mesh<STATS>(p, O, D, invD, th, n_nodes, n_tris);
-
-        if (iS < 0 && th.id < 0) {                 // Miss(): Distance = -1
-            finalColor = finalColor + contribution * ambientColor;
-            break;
+    F3 O = s.O, D = s.D;
+    // TraceRay (Renderer.cpp:231-301)
+    float tS = FLT_MAX; int iS = -1;
+    Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
+    if (MODE == RT_MODE_SPHERES || MODE == RT_MODE_BOTH) trace_spheres(p, O, D, tS, iS);
+    if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) {
+        if (have_mesh_hit) th = mesh_hit;                   // found by the whole wave (zero direction component)
+        else {
+            F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);  // Renderer.cpp:151
+            trace_mesh<STATS>(p, O, D, invD, th, n_nodes, n_tris);
         }
-        F3 P, N;
-        uint32_t matIndex;
-        if (tS < th.t) {                            // ClosestHitSphere (Renderer.cpp:303-317)
-            float4 sp = p.spheres[iS];
-            P = O + D * tS;
-            N = normalize3(P - f3(sp.x, sp.y, sp.z));
-            matIndex = p.sphere_mat[iS];
-            if (i == 0) primary_id = iS;
-        } else {                                    // ClosestHitTriangle (Renderer.cpp:319-332)
-            const float4* sh = p.trishade + 3 * (size_t)th.id;
-            float4 s0 = sh[0], s1 = sh[1], s2 = sh[2];
-            P = O + D * th.t;
-            F3 nrm = (f3(s0.x, s0.y, s0.z) * ((1.0f - th.u) - th.v) + f3(s0.w, s1.x, s1.y) * th.u)
-                     + f3(s1.z, s1.w, s2.x) * th.v;
-            N = normalize3(nrm);
-            matIndex = __float_as_uint(s2.y);
-            if (i == 0) primary_id = RT_ID_TRI_BIT | th.id;
-        }
-
-        const float4 m0 = p.materials[3 * matIndex];       // albedo.rgb, roughness
-        const float4 m1 = p.materials[3 * matIndex + 1];   // emission.rgb, transparency
-        bool hitInside = dot3(D, N) > 0.0f;
-        F3 normalSurface = hitInside ? -N : N;
-        O = P + normalSurface * EPSILON;
-
-        if (m1.w > 0.0f) {                          // always transmit (Renderer.cpp:176-197)
-            const float IOR = p.materials[3 * matIndex + 2].x;
-            // RefractionRay (Renderer.cpp:334-361)
-            F3 ref_n = N;
-            float eta_t = IOR, eta_i = 1.0f;
-            float i_dot_n = dot3(D, N);
-            if (i_dot_n < 0.0f) i_dot_n = -i_dot_n;
-            else { ref_n = -N; eta_t = 1.0f; eta_i = IOR; }
-            float eta = eta_i / eta_t;
-            float k = 1.0f - (eta * eta) * (1.0f - i_dot_n * i_dot_n);
-            if (!(k < 0.0f)) {
-                O = P + ref_n * (-EPSILON);
-                D = normalize3((D + ref_n * i_dot_n) * eta - ref_n * sqrtf(k));
-                continue;                           // skips emission, albedo and roulette
-            }
-            // total internal reflection: fall through with D unchanged
-        } else {
-            F3 diffuseRayDir = normalize3(N + random_unit_vector(rng));
-            F3 reflectedVector = reflect3(D, N);
-            D = normalize3(mix3(reflectedVector, diffuseRayDir, m0.w * m0.w));
-        }
-
-        finalColor = finalColor + f3(m1.x, m1.y, m1.z) * contribution;
-        contribution = contribution * f3(m0.x, m0.y, m0.z);
-
-        float pr = sel_max(contribution.x, sel_max(contribution.y, contribution.z));
-        if (rng_float(rng) > pr) break;
-        contribution = contribution * (1.0f / pr);
     }
-    return finalColor;
+
+    if (iS < 0 && th.id < 0) {                             // Miss(): finalColor += contribution * ambient (= 0), break
+        s.finalColor = s.finalColor + s.contribution * f3(0.0f, 0.0f, 0.0f);
+        if (primary_id && first) *primary_id = -1;
+        return true;
+    }
+    F3 P, N;
+    uint32_t matIndex;
+    if (tS < th.t) {                                        // ClosestHitSphere (Renderer.cpp:303-317)
+        const float4 sp = p.spheres[iS];                  // per-lane index: vector load
+        P = O + D * tS;
+        N = normalize3(P - f3(sp.x, sp.y, sp.z));
+        matIndex = p.sphere_mat[iS];
+        if (primary_id && first) *primary_id = iS;
+    } else {                                                // ClosestHitTriangle (Renderer.cpp:319-332)
+        const float4* sh = p.trishade + 3 * (size_t)th.id;
+        float4 s0 = sh[0], s1 = sh[1], s2 = sh[2];
+        P = O + D * th.t;
+        F3 nrm = (f3(s0.x, s0.y, s0.z) * ((1.0f - th.u) - th.v) + f3(s0.w, s1.x, s1.y) * th.u) + f3(s1.z, s1.w, s2.x) * th.v;
+        N = normalize3(nrm);
+        matIndex = __float_as_uint(s2.y);
+        if (primary_id && first) *primary_id = RT_ID_TRI_BIT | th.id;
+    }
+
+    const float4 m0 = p.materials[3 * matIndex];           // albedo.rgb, roughness
+    const float4 m1 = p.materials[3 * matIndex + 1];       // emission.rgb, transparency
+    bool hitInside = dot3(D, N) > 0.0f;
+    F3 normalSurface = hitInside ? -N : N;
+    s.O = P + normalSurface * EPSILON;
+
+    if (m1.w > 0.0f) {                                      // always transmit (Renderer.cpp:176-197)
+        const float IOR = p.materials[3 * matIndex + 2].x;
+        // RefractionRay (Renderer.cpp:334-361)
+        F3 ref_n = N;
+        float eta_t = IOR, eta_i = 1.0f;
+        float i_dot_n = dot3(D, N);
+        if (i_dot_n < 0.0f) i_dot_n = -i_dot_n;
+        else { ref_n = -N; eta_t = 1.0f; eta_i = IOR; }
+        float eta = eta_i / eta_t;
+        float k = 1.0f - (eta * eta) * (1.0f - i_dot_n * i_dot_n);
+        if (!(k < 0.0f)) {
+            s.O = P + ref_n * (-EPSILON);
+            s.D = normalize3((D + ref_n * i_dot_n) * eta - ref_n * sqrtf(k));
+            return last;                                    // "continue": skips emission, albedo and roulette
+        }
+        // total internal reflection: falls through with the direction unchanged
+    } else {
+        F3 diffuseRayDir = normalize3(N + random_unit_vector(s.rng));
+        F3 reflectedVector = reflect3(D, N);
+        s.D = normalize3(mix3(reflectedVector, diffuseRayDir, m0.w * m0.w));
+    }
+
+    s.finalColor = s.finalColor + f3(m1.x, m1.y, m1.z) * s.contribution;
+    s.contribution = s.contribution * f3(m0.x, m0.y, m0.z);
+
+    float pr = sel_max(s.contribution.x, sel_max(s.contribution.y, s.contribution.z));
+    if (rng_float(s.rng) > pr) return true;                 // Russian roulette (Renderer.cpp:218-225)
+    s.contribution = s.contribution * (1.0f / pr);
+    return last;
+}
+
+// Pixel `slot` of work unit `unit`: units are the four 8x2 strips of each 8x8 tile of the 16-row bands this context
+// renders; tiles are numbered down the columns, so the pixels of one image column (the default camera's centre column is the
+// expensive one for meshes) fall into consecutive units and therefore onto different waves.
+__device__ __forceinline__ bool unit_pixel(const RtParams& p, uint32_t unit, uint32_t slot, uint32_t& pixel)
+{
+    const uint32_t tile = unit >> 2;
+    const uint32_t within = ((unit & 3u) << 4) | slot;
+    const uint32_t tcol = tile / p.tile_rows, trow = tile - tcol * p.tile_rows;
+    const uint32_t band = (trow >> 1) * p.band_count + p.band_index;
+    const uint32_t x = tcol * 8u + (within & 7u);
+    const uint32_t y = band * RT_TILE + (trow & 1u) * 8u + (within >> 3);
+    pixel = y * p.width + x;
+    return x < p.width && y < p.height;
 }
 
 }  // namespace
 
 // ---- kernels ------------------------------------------------------------------------------------------------------
-// grid = (ceil(w/16), bands owned by this context); 256 threads = 4 waves, each an 8x8 pixel tile, so a wave's accumulation
-// and image accesses are eight 128-byte row segments.
+// Camera::RecalculateRayDirections (Camera.cpp:134-150): one direction per pixel, cached in HBM until the camera or the
+// frame size changes -- as the reference caches them in the Camera.
+__global__ __launch_bounds__(256) void rt_raygen_kernel(RtParams p)
+{
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= p.width * p.height) return;
+    const uint32_t y = pixel / p.width, x = pixel - y * p.width;
+    F3 d = camera_dir(p, x, y);
+    p.dirs_out[pixel] = make_float4(d.x, d.y, d.z, 0.0f);
+}
+
+// The trace kernel is persistent: the grid is sized to what the chip holds at once and every wave walks its own list of
+// pixel tiles.  Each loop iteration advances every live lane by one bounce; lanes whose path ended take the next
+// (pixel, frame) before the next iteration, so the wave stays full until its list runs dry.  A lane keeps its pixel for all
+// n_frames frames and adds them in frame order, which makes the sum identical to n_frames separate Render calls.
+// The frame's RT_UNIT-pixel units are dealt round-robin over the waves (no shared counter: one atomic word serves only ~88
+// requests per microsecond, too few for a 0.2 ms frame), so every wave gets the same number of units to within one.
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
 {
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * RT_TILE + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t band = blockIdx.y * p.band_count + p.band_index;
-    const uint32_t y = band * RT_TILE + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t unit = wave, slot = 0;                         // wave-uniform: current work unit (wave, wave + n_waves, ...) and its first free pixel
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
 
-    if (x < p.width && y < p.height) {
-        const uint32_t pixel = y * p.width + x;
-        const F3 camPos = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-        F3 dir;
-        if (p.ray_dirs) dir = f3(p.ray_dirs[3 * (size_t)pixel], p.ray_dirs[3 * (size_t)pixel + 1], p.ray_dirs[3 * (size_t)pixel + 2]);
-        else dir = camera_dir(p, x, y);
+    bool live = false;
+    uint32_t pixel = 0, frame = 0;
+    F3 acc = f3(0.0f, 0.0f, 0.0f);
+    Path s;
+    s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0;
 
-        F3 acc = f3(0.0f, 0.0f, 0.0f);              // frame 1 restarts accumulation (Renderer.cpp:55-56)
-        if (p.frame_first != 1u) { float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
-
-        int32_t first_id = -1;
-        for (uint32_t f = 0; f < p.n_frames; ++f) {
-            const uint32_t frame = p.frame_first + f;
-            int32_t id;
-            F3 color = per_pixel<MODE, STATS>(p, camPos, dir, pixel_seed(pixel, frame, p.seed), id, n_rays, n_nodes, n_tris);
-            if (f == 0) first_id = id;
-            acc = acc + color;                      // m_AccumulationBuffer[pixelIndex] += pixelColor
+    for (;;) {
+        // ---- give every idle lane a pixel while this wave has units left
+        unsigned long long need = __ballot(!live);
+        while (need != 0ull && unit < p.n_units) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t avail = RT_UNIT - slot;
+            if (!live && rank < avail && unit_pixel(p, unit, slot + rank, pixel)) {
+                live = true;
+                frame = 0;
+                acc = f3(0.0f, 0.0f, 0.0f);                 // frame index 1 restarts accumulation (Renderer.cpp:55-56)
+                if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+                path_begin(s, p, pixel, p.frame_first);
+            }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            slot += wanted < avail ? wanted : avail;
+            if (slot == RT_UNIT) { unit += n_waves; slot = 0; }
+            need = __ballot(!live);                         // lanes beyond this unit, and lanes whose pixel fell outside the frame
         }
-        p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-        p.image[pixel] = resolve_px(acc, (float)(p.frame_first + p.n_frames - 1u), p.use_ace);
-        if (p.primary_ids) p.primary_ids[pixel] = first_id;
-        if (p.out_dirs) {
-            p.out_dirs[3 * (size_t)pixel] = dir.x; p.out_dirs[3 * (size_t)pixel + 1] = dir.y; p.out_dirs[3 * (size_t)pixel + 2] = dir.z;
+        if (__ballot(live) == 0ull) break;                  // nothing in flight and nothing left to take
+
+        // ---- rays the tree cannot prune (a zero direction component): the wave walks the tree for them, one at a time
+        bool have_mesh_hit = false;
+        Hit mesh_hit; mesh_hit.t = FLT_MAX; mesh_hit.id = -1; mesh_hit.u = 0.0f; mesh_hit.v = 0.0f;
+        if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) {
+            const bool unprunable = live && s.bounce < p.bounces && s.D.x == 0.0f;
+            unsigned long long todo = __ballot(unprunable);
+            while (todo != 0ull) {
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
+                const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
+                const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                Hit h;
+                uint32_t cn = 0, ct = 0;
+                const bool ok = trace_mesh_cooperative<STATS>(p, O, D, invD, lane, h, cn, ct);
+                if (ok) {
+                    if ((int)lane == src) { have_mesh_hit = true; mesh_hit = h; }
+                    n_nodes += cn; n_tris += ct;            // counted by the lanes that did the work
+                }
+            }
+        }
+
+        // ---- one bounce for every lane with a path
+        if (live) {
+            int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
+            if (path_step<MODE, STATS>(s, p, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris)) {
+                if (id_out && p.bounces == 0) *id_out = -1;
+                acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
+                frame++;
+                if (frame < p.n_frames) path_begin(s, p, pixel, p.frame_first + frame);
+                else { p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f); live = false; }
+            }
         }
     }
 
-    // work counters: one slot group per workgroup, summed on the host when read
+    // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
-        unsigned long long* slot = p.counters + 4 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+        unsigned long long* slot = p.counters + 4 * (size_t)wave;
         uint32_t r = n_rays, n = n_nodes, t = n_tris;
         for (int off = 32; off > 0; off >>= 1) {
             r += __shfl_down(r, off); n += __shfl_down(n, off); t += __shfl_down(t, off);
         }
         if (lane == 0) {
-            atomicAdd(&slot[0], (unsigned long long)r);
-            if (STATS) { atomicAdd(&slot[1], (unsigned long long)n); atomicAdd(&slot[2], (unsigned long long)t); }
-            if (MODE != RT_MODE_MESH) atomicAdd(&slot[3], (unsigned long long)r * p.n_spheres);
+            slot[0] += (unsigned long long)r;
+            if (STATS) { slot[1] += (unsigned long long)n; slot[2] += (unsigned long long)t; }
+            if (MODE != RT_MODE_MESH) slot[3] += (unsigned long long)r * p.n_spheres;
         }
     }
 }
 
-// Resolve only (Renderer.cpp:68-79): image = tonemap(accum / frame_index)
+// Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
 __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t frame_index)
 {
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -446,8 +636,8 @@ __global__ __launch_bounds__(256) void rt_aa_kernel(RtParams p, uint32_t frame_i
     for (int yo = -1; yo <= 1; ++yo)
         for (int xo = -1; xo <= 1; ++xo) {
             const int xx = (int)x + xo, yy = (int)y + yo;
-            const int s = xo + yo;
-            if ((s < 0 ? -s : s) > 1 || xx < 0 || xx >= (int)p.width || yy < 0 || yy >= (int)p.height) continue;
+            const int sum = xo + yo;
+            if ((sum < 0 ? -sum : sum) > 1 || xx < 0 || xx >= (int)p.width || yy < 0 || yy >= (int)p.height) continue;
             const float wgt = 1.0f - ((float)((yo < 0 ? -yo : yo) + (xo < 0 ? -xo : xo)) * 0.5f);
             float4 a = p.accum[(uint32_t)yy * p.width + (uint32_t)xx];
             acc = acc + f3(a.x, a.y, a.z) * wgt;
@@ -458,21 +648,46 @@ __global__ __launch_bounds__(256) void rt_aa_kernel(RtParams p, uint32_t frame_i
 }
 
 // ---- launchers (called from rt_api.cpp) -----------------------------------------------------------------------------
-template <int MODE>
-static void launch_mode(const RtParams& p, dim3 grid, bool stats, hipStream_t s)
+template <int MODE, bool STATS>
+static hipError_t occupancy_of(int* blocks_per_cu)
 {
-    if (stats) hipLaunchKernelGGL((rt_trace_kernel<MODE, true>), grid, dim3(256), 0, s, p);
-    else       hipLaunchKernelGGL((rt_trace_kernel<MODE, false>), grid, dim3(256), 0, s, p);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, rt_trace_kernel<MODE, STATS>, 256, 0);
 }
 
-extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned gx, unsigned gy, hipStream_t s)
+// Resident workgroups per CU of the trace kernel for (mode, stats): sizes the persistent grid.
+extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int* blocks_per_cu)
 {
-    dim3 grid(gx, gy);
+    switch (mode * 2 + (stats ? 1 : 0)) {
+    case 0: return occupancy_of<RT_MODE_MESH, false>(blocks_per_cu);
+    case 1: return occupancy_of<RT_MODE_MESH, true>(blocks_per_cu);
+    case 2: return occupancy_of<RT_MODE_SPHERES, false>(blocks_per_cu);
+    case 3: return occupancy_of<RT_MODE_SPHERES, true>(blocks_per_cu);
+    case 4: return occupancy_of<RT_MODE_BOTH, false>(blocks_per_cu);
+    default: return occupancy_of<RT_MODE_BOTH, true>(blocks_per_cu);
+    }
+}
+
+template <int MODE>
+static void launch_mode(const RtParams& p, unsigned grid, bool stats, hipStream_t s)
+{
+    if (stats) hipLaunchKernelGGL((rt_trace_kernel<MODE, true>), dim3(grid), dim3(256), 0, s, p);
+    else       hipLaunchKernelGGL((rt_trace_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, p);
+}
+
+extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned grid, hipStream_t s)
+{
     switch (mode) {
     case RT_MODE_MESH:    launch_mode<RT_MODE_MESH>(*p, grid, stats != 0, s); break;
     case RT_MODE_SPHERES: launch_mode<RT_MODE_SPHERES>(*p, grid, stats != 0, s); break;
     default:              launch_mode<RT_MODE_BOTH>(*p, grid, stats != 0, s); break;
     }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s)
+{
+    const unsigned n = p->width * p->height;
+    hipLaunchKernelGGL(rt_raygen_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 
