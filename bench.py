@@ -109,8 +109,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # RT_BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, RCCL sum, rank-0 resolve) even with one rank,
+    # so it can be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("RT_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
@@ -129,18 +133,18 @@ def main():
     r.upload(scene, cam)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     # frame indices of this rank: sample split (world == 1: 1, 2, 3, ...)
     warm = rtd.frames_for_rank(rank, world, W)
     frames = rtd.frames_for_rank(rank, world, K, first=1)
-    acc_t = rtd.accum_tensor(r) if world > 1 else None
+    acc_t = rtd.accum_tensor(r) if use_dist else None
 
     r.reset_accum()
     for f in warm:
         r.render_only(f + 1000)                      # warmup only heats caches/clocks; its sum is discarded
-    if world > 1:
+    if use_dist:
         rtd.sum_accumulation(acc_t)
     r.sync(); torch.cuda.synchronize(); barrier()
     r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
@@ -149,7 +153,7 @@ def main():
     t0 = time.perf_counter()
     for f in frames:                                 # every rank starts from a zeroed buffer (rt_reset_accum)
         r.render_only(f)
-    if world > 1:
+    if use_dist:
         rtd.sum_accumulation(acc_t)
         if rank == 0:
             r.resolve(world * K)
@@ -159,7 +163,7 @@ def main():
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     cnt = r.read_counters()
     rays_t = torch.tensor([float(cnt.rays)], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays_t, op=dist.ReduceOp.SUM)
     dt_max, rays_total = float(dt_t.item()), float(rays_t.item())
@@ -200,7 +204,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "width": w, "height": h, "bounces": cfg["bounces"],
-                       "frames_per_gpu": K, "split": "sample" if world > 1 else "none",
+                       "frames_per_gpu": K, "split": "sample" if use_dist else "none",
                        "rays_per_frame": rays_total / (K * world), "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
@@ -209,7 +213,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

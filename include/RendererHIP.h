@@ -1,0 +1,181 @@
+// RendererHIP.h -- drop-in for the reference's `Renderer` (RayTracer/src/Renderer.h:101-161) on top of the C ABI in
+// rt_mi355x.h.  Header-only C++17; link librt_mi355x.so.
+//
+// Same public members, same meaning:
+//     Settings& GetSettings();  void OnResize(w, h);  void Render(const Scene&, const Camera&);
+//     std::shared_ptr<Image> GetImage();  void ResetFrameIndex();  uint32_t GetFrameIndex();
+// so RaytracerLayer (RayTracer/src/RaytracerApp.cpp:259-366) compiles against it unchanged:
+//     using Renderer = RendererHIP<Scene, Camera, Walnut::Image, Walnut::ImageFormat::RGBA32F>;
+//
+// The template parameters are the reference's own types (Scene.h:37-44, Camera.h:6-48, Walnut/Image.h:16-52); they are
+// parameters only so that this header can also be instantiated with light stand-ins where Vulkan is absent.
+// What is read from them:
+//   SceneT : spheres[i].{Position,Radius,MaterialIndex}, materials[i].{Albedo,Emission,Roughness,Transparency,IOR},
+//            triangles[i].{Normals[0..2],MaterialIndex}, kd_tree (smart pointer to KDTreeCPU: getRootNode, getMeshVerts,
+//            getMeshTris, getMeshNumVerts, getMeshNumTris)
+//   CameraT: GetPosition(), GetInverseProjection(), GetInverseView() (glm types: contiguous floats, column-major)
+//   ImageT : ImageT(w, h, kFormat), GetWidth(), GetHeight(), Resize(w, h), SetData(const void*); kFormat is the image
+//            type's RGBA32F enumerator (Walnut/Image.h:9-14)
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "rt_mi355x.h"
+
+// Flattens the pointer tree under KDTreeCPU::getRootNode() (KDAccel/KDTreeCPU.cpp:73-76; node fields
+// KDAccel/KDTreeStructs.h:55-76) into the arrays rt_set_kdtree takes.  Preorder, left before right; only leaves keep
+// their triangle lists.
+struct RtFlatTree {
+    std::vector<float> center, extent;
+    std::vector<int32_t> left, right, first, count, leaf_idx;
+    rt_kd_flat view() const
+    {
+        rt_kd_flat f;
+        f.n_nodes = (uint32_t)left.size(); f.center = center.data(); f.extent = extent.data();
+        f.left = left.data(); f.right = right.data(); f.first = first.data(); f.count = count.data();
+        f.n_leaf_idx = (uint32_t)leaf_idx.size(); f.leaf_idx = leaf_idx.data();
+        return f;
+    }
+};
+
+template <class NodeT>
+inline void rt_flatten_kdtree(const NodeT* root, RtFlatTree& out)
+{
+    out = RtFlatTree();
+    struct Item { const NodeT* node; int32_t parent; bool is_left; };
+    std::vector<Item> stack{{root, -1, false}};
+    while (!stack.empty()) {
+        Item it = stack.back(); stack.pop_back();
+        const NodeT* n = it.node;
+        const int32_t me = (int32_t)out.left.size();
+        if (it.parent >= 0) (it.is_left ? out.left : out.right)[(size_t)it.parent] = me;
+        for (int k = 0; k < 3; ++k) { out.center.push_back(n->bbox.center[k]); out.extent.push_back(n->bbox.extends[k]); }
+        out.left.push_back(-1); out.right.push_back(-1);
+        if (!n->left && !n->right) {
+            out.first.push_back((int32_t)out.leaf_idx.size()); out.count.push_back(n->num_tris);
+            out.leaf_idx.insert(out.leaf_idx.end(), n->tri_indices, n->tri_indices + n->num_tris);
+        } else { out.first.push_back(0); out.count.push_back(0); }
+        if (n->right) stack.push_back({n->right, me, false});      // popped after the left child: preorder
+        if (n->left) stack.push_back({n->left, me, true});
+    }
+}
+
+template <class SceneT, class CameraT, class ImageT, auto kFormat>
+class RendererHIP {
+public:
+    struct Settings {                      // Renderer::Settings (Renderer.h:103-110)
+        bool Render = true;
+        bool Accumulate = true;
+        bool UseSphereScene = false;
+        bool UseACE_Color = true;
+        bool AntiAliasing = false;
+        uint32_t Bounces = 8;
+    };
+    Settings& GetSettings() { return m_settings; }
+
+    explicit RendererHIP(int device = 0) : m_ctx(rt_create(device))
+    {
+        if (!m_ctx) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+    }
+    ~RendererHIP() { rt_destroy(m_ctx); }
+    RendererHIP(const RendererHIP&) = delete;
+    RendererHIP& operator=(const RendererHIP&) = delete;
+
+    // Renderer::OnResize (Renderer.cpp:20-43)
+    void OnResize(uint32_t width, uint32_t height)
+    {
+        if (m_Image) {
+            if (m_Image->GetWidth() == width && m_Image->GetHeight() == height) return;
+            m_Image->Resize(width, height);
+        } else {
+            m_Image = std::make_shared<ImageT>(width, height, kFormat);
+        }
+        check(rt_resize(m_ctx, width, height), "rt_resize");
+        m_ImageData.assign((size_t)4 * width * height, 0.0f);
+        ResetFrameIndex();
+    }
+
+    // Renderer::Render (Renderer.cpp:45-135): on return the image object holds the new frame.
+    void Render(const SceneT& scene, const CameraT& camera)
+    {
+        rt_settings st;
+        st.accumulate = m_settings.Accumulate; st.scene_mode = m_settings.UseSphereScene ? RT_SCENE_SPHERES : RT_SCENE_MESH;
+        st.use_ace = m_settings.UseACE_Color; st.anti_aliasing = m_settings.AntiAliasing;
+        st.bounces = m_settings.Bounces; st.seed = 1337;
+        check(rt_set_settings(m_ctx, &st), "rt_set_settings");
+
+        // spheres and materials are edited live by the UI (RaytracerApp.cpp:283-331): sent every frame (a few hundred bytes)
+        m_spheres.resize(scene.spheres.size());
+        for (size_t i = 0; i < scene.spheres.size(); ++i) {
+            const auto& s = scene.spheres[i];
+            m_spheres[i] = rt_sphere{s.Position[0], s.Position[1], s.Position[2], s.Radius, (uint32_t)s.MaterialIndex};
+        }
+        m_materials.resize(scene.materials.size());
+        for (size_t i = 0; i < scene.materials.size(); ++i) {
+            const auto& m = scene.materials[i];
+            m_materials[i] = rt_material{{m.Albedo[0], m.Albedo[1], m.Albedo[2]}, {m.Emission[0], m.Emission[1], m.Emission[2]},
+                                         m.Roughness, m.Transparency, m.IOR};
+        }
+        check(rt_set_materials(m_ctx, m_materials.data(), (uint32_t)m_materials.size()), "rt_set_materials");
+        check(rt_set_spheres(m_ctx, m_spheres.data(), (uint32_t)m_spheres.size()), "rt_set_spheres");
+
+        // mesh + KD tree are immutable after the layer's constructor (RaytracerApp.cpp:130): uploaded once per tree object
+        if (scene.kd_tree && (const void*)&*scene.kd_tree != m_tree_key) upload_mesh(scene);
+
+        const auto& pos = camera.GetPosition();
+        const float p3[3] = {pos[0], pos[1], pos[2]};
+        check(rt_set_camera(m_ctx, p3, &camera.GetInverseProjection()[0][0], &camera.GetInverseView()[0][0]), "rt_set_camera");
+
+        check(rt_render(m_ctx, m_frameindex), "rt_render");
+        if (m_settings.Accumulate) m_frameindex++; else m_frameindex = 1;      // Renderer.cpp:128-131
+        check(rt_read_image(m_ctx, m_ImageData.data()), "rt_read_image");
+        m_Image->SetData(m_ImageData.data());                                   // Renderer.cpp:134
+    }
+
+    std::shared_ptr<ImageT> GetImage() { return m_Image; }
+    void ResetFrameIndex() { m_frameindex = 1; }
+    uint32_t GetFrameIndex() { return m_frameindex; }
+
+    rt_ctx* context() { return m_ctx; }
+
+private:
+    void check(int rc, const char* what)
+    {
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_last_error(m_ctx));
+    }
+
+    void upload_mesh(const SceneT& scene)
+    {
+        const auto& kd = *scene.kd_tree;
+        const uint32_t nverts = (uint32_t)kd.getMeshNumVerts(), ntris = (uint32_t)kd.getMeshNumTris();
+        std::vector<float> verts((size_t)3 * nverts), normals((size_t)9 * ntris);
+        std::vector<uint32_t> idx((size_t)3 * ntris), mats(ntris);
+        for (uint32_t i = 0; i < nverts; ++i) for (int k = 0; k < 3; ++k) verts[3 * (size_t)i + k] = kd.getMeshVerts()[i][k];
+        for (uint32_t t = 0; t < ntris; ++t) {
+            for (int k = 0; k < 3; ++k) idx[3 * (size_t)t + k] = kd.getMeshTris()[t][k];
+            const auto& tri = scene.triangles[t];
+            for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) normals[9 * (size_t)t + 3 * c + k] = tri.Normals[c][k];
+            mats[t] = (uint32_t)tri.MaterialIndex;
+        }
+        check(rt_set_mesh(m_ctx, verts.data(), nverts, idx.data(), normals.data(), mats.data(), ntris), "rt_set_mesh");
+        RtFlatTree flat;
+        rt_flatten_kdtree(kd.getRootNode(), flat);
+        const rt_kd_flat view = flat.view();
+        check(rt_set_kdtree(m_ctx, &view), "rt_set_kdtree");
+        m_tree_key = (const void*)&kd;
+    }
+
+    rt_ctx* m_ctx;
+    Settings m_settings;
+    std::shared_ptr<ImageT> m_Image;
+    std::vector<float> m_ImageData;
+    std::vector<rt_sphere> m_spheres;
+    std::vector<rt_material> m_materials;
+    const void* m_tree_key = nullptr;
+    uint32_t m_frameindex = 1;
+};

@@ -48,7 +48,7 @@ def image_tensor(renderer):
 def sum_accumulation(accum, group=None):
     """Sample split: sum the per-rank accumulation buffers in place on every rank."""
     import torch.distributed as dist
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized():
         dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
     return accum
 

@@ -376,3 +376,84 @@ def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
     osc.render_frame(orc.Settings(1, 0, 1, 0, 8), cam.GetPosition(), dirs, w, h, 1, acc, img, nthreads=16, row_step=16)
     rows = np.arange(0, h, 16)
     assert np.array_equal(bits(renderer.read_accum()[rows]), bits(acc.reshape(h, w, 3)[rows]))
+
+
+# ---- plumbing for the multi-GPU path, on one GPU ------------------------------------------------------------------------------
+def test_accum_tensor_aliases_the_device_buffer(rt, orc, renderer):
+    """raytracer_amd.dist hands torch a zero-copy view of the accumulation buffer (what the RCCL sum runs on)."""
+    import torch
+    from raytracer_amd import dist as rtd
+    scene, osc = make_scene(rt, orc)
+    got, want = run_both(rt, orc, renderer, scene, osc, 64, 48, 1, 5, 2)
+    t = rtd.accum_tensor(renderer)
+    assert t.shape == (48, 64, 4) and t.is_cuda
+    assert np.array_equal(bits(t[..., :3].cpu().numpy().reshape(-1, 3)), bits(want["acc"]))
+    t.mul_(2.0)                                   # written through torch ...
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(want["acc"] * np.float32(2.0)))   # ... seen by the library
+    renderer.resolve(2)
+    img = renderer.read_image().reshape(-1, 4)
+    ref = np.zeros(3, np.float32); out = np.zeros(3, np.float32)
+    import ctypes as C
+    for i in (0, 777, 3071):
+        ref[:] = want["acc"][i] * np.float32(2.0) / np.float32(2.0)
+        orc.lib().orc_tonemap(ref.ctypes.data_as(C.c_void_p), 1, 1, out.ctypes.data_as(C.c_void_p))
+        assert np.array_equal(bits(img[i, :3]), bits(out))
+
+
+def test_bench_distributed_code_path_with_one_rank():
+    """bench.py under torch.distributed.run with RCCL (one rank, RT_BENCH_FORCE_DIST=1): process group, sum of the
+    accumulation buffers, rank-0 resolve and the JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_BENCH_FORCE_DIST="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--config", "1",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["config"]["split"] == "sample"
+    assert d["roofline"]["frac"] > 0 and d["unit"] == "Mrays/s"
+
+
+# ---- the drop-in itself: RendererHIP with the reference's own Scene / Camera / KDTreeCPU ------------------------------------------
+@pytest.mark.parametrize("use_spheres", [1, 0])
+def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
+    """oracle/_ref/renderer_hip_demo links the reference's unmodified Scene.h, Camera.cpp and KDTreeCPU (its real builder)
+    with include/RendererHIP.h in place of Renderer; what it hands to Image::SetData and its accumulation buffer must equal
+    the oracle's.  (The binary is built where the reference tree exists and travels with the repo.)"""
+    import subprocess
+    from raytracer_amd import scenes
+    demo = os.path.join(ROOT, "oracle", "_ref", "renderer_hip_demo")
+    if not os.path.exists(demo):
+        pytest.skip("oracle/_ref/renderer_hip_demo not built (reference tree absent at build time)")
+    w, h, frames, bounces = 96, 64, 3, 5 if use_spheres else 4
+    spheres, mats = scenes.default_spheres(), scenes.default_materials()
+    verts, tris, normals9, tri_mat, mesh_mats = scenes.displaced_grid(20, mat_offset=len(mats))
+    mats = np.concatenate([mats, mesh_mats])
+    with open(tmp_path / "scene.bin", "wb") as f:
+        f.write(np.array([w, h, frames, bounces, use_spheres, len(spheres), len(mats), len(verts), len(tris)], np.uint32).tobytes())
+        f.write(spheres.tobytes()); f.write(mats.tobytes())
+        f.write(verts.astype(np.float32).tobytes()); f.write(tris.astype(np.uint32).tobytes())
+        f.write(normals9.astype(np.float32).tobytes()); f.write(tri_mat.astype(np.uint32).tobytes())
+    p = subprocess.run([demo, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:] + p.stdout[-500:]
+    raw = np.fromfile(tmp_path / "out.bin", np.uint8)
+    tail = raw[:8].view(np.uint32)
+    img = raw[8:8 + w * h * 16].view(np.float32).reshape(-1, 4)
+    acc = raw[8 + w * h * 16:].view(np.float32).reshape(-1, 3)
+    assert tail[0] == frames + 1
+
+    osc = orc.Scene()
+    osc.set_spheres(spheres); osc.set_materials(mats); osc.set_mesh(verts, tris, normals9, tri_mat); osc.build_kd()
+    assert tail[1] == len(osc.export_kd()["left"])                       # the reference builder's node count
+    cam = orc.camera(70.0, 0.05, 100.0, w, h)
+    o_acc = np.zeros((h * w, 3), np.float32); o_img = np.zeros((h * w, 4), np.float32)
+    st = orc.Settings(1, 1 if use_spheres else 0, 1, 0, bounces)
+    for fr in range(1, frames + 1):
+        osc.render_frame(st, cam["pos"], cam["dirs"], w, h, fr, o_acc, o_img)
+    assert np.array_equal(bits(acc), bits(o_acc))
+    assert np.array_equal(bits(img), bits(o_img))
