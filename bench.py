@@ -29,8 +29,9 @@ FLOPS_PER_SPHERE_RAY = lambda n_spheres: 6 + 24 * n_spheres + 120   # intersecti
 FLOPS_PER_PIXEL_RESOLVE = 40
 BYTES_PER_PIXEL_FRAME = 40          # accumulation read 12 + write 12 + RGBA32F write 16
 BYTES_PER_NODE, BYTES_PER_TRI, BYTES_PER_HIT = 32, 40, 40
-PEAK_VALU_NOFMA_TFLOPS = 39.3       # 256 CU x 64 lanes/clk x 2.4 GHz, one op per lane (no FMA, unpacked)
-PEAK_VALU_NOFMA_PACKED_TFLOPS = 78.6
+# fp32 VALU ceiling without FMA: the chip's 157.3 TFLOP/s vector peak counts an FMA as two operations, and this path may not
+# fuse (bit-exact contract), so one operation per lane per issue slot: 256 CU x 128 lanes/clk x 2.4 GHz.
+PEAK_VALU_NOFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
 
 CONFIGS = {
@@ -178,7 +179,6 @@ def main():
             achieved = flops / avg_kernel_s / 1e12
             roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": _traffic_from_profile(args.config),
-                    "peak_packed": PEAK_VALU_NOFMA_PACKED_TFLOPS, "frac_packed": achieved / PEAK_VALU_NOFMA_PACKED_TFLOPS,
                     "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
                     "kernel": "rt_trace_kernel<spheres>", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
                     "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
