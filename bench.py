@@ -69,7 +69,6 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
     if scene.kd_tree is not None:
         oscene.set_mesh(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat)
         oscene.import_kd(scene.kd_tree.arrays())
-        row_step = 8                                      # mesh frames are ~10x dearer: every 8th row
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
     st = orc.Settings(1, cfg["mode"], 1, 0, cfg["bounces"])
     acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
@@ -209,7 +208,7 @@ def main():
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
-            n = args.cpu_frames or (4 if cfg["mode"] == 1 else 2)
+            n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work
             out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
         print(json.dumps(out), flush=True)
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries of tools/profile.sh from gpurun_out/ into profiles/ (tracked) under a round tag, and derive
+profiles/traffic.json (HBM bytes per trace-kernel launch: 2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE doubled because gfx950
+reports half of the bytes of wide coalesced reads; both counters are in KiB)."""
+import glob, json, os, shutil, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+traffic_path = os.path.join(root, "profiles", "traffic.json")
+traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+for cfg in (1, 2, 3):
+    d = os.path.join(root, "gpurun_out", "prof_cfg%d" % cfg)
+    summ = os.path.join(root, "gpurun_out", "prof_cfg%d_summary.json" % cfg)
+    if not os.path.exists(summ):
+        continue
+    for f in glob.glob(d + "/trace/**/*_kernel_stats.csv", recursive=True):
+        shutil.copy(f, os.path.join(root, "profiles", "%s_cfg%d_kernel_stats.csv" % (tag, cfg)))
+    shutil.copy(summ, os.path.join(root, "profiles", "%s_cfg%d_pmc_summary.json" % (tag, cfg)))
+    b = os.path.join(root, "gpurun_out", "bench_cfg%d.json" % cfg)
+    if os.path.exists(b):
+        shutil.copy(b, os.path.join(root, "profiles", "%s_cfg%d_bench.json" % (tag, cfg)))
+    s = json.load(open(summ))
+    for k, cs in s["counters"].items():
+        if "rt_trace_kernel" in k and "false" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            traffic["config%d" % cfg] = {
+                "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
+                "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0,
+                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh %d, round tag %s" % (cfg, tag)}
+json.dump(traffic, open(traffic_path, "w"), indent=1)
+print(json.dumps(traffic, indent=1))
