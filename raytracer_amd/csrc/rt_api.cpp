@@ -17,6 +17,8 @@
 extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned grid, hipStream_t s);
 extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int* blocks_per_cu);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
+extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 
@@ -71,6 +73,15 @@ struct rt_ctx {
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
     bool use_host_dirs = false;          // d_dirs holds directions the host supplied (rt_set_ray_dirs)
     bool dirs_dirty = true;              // d_dirs must be regenerated from the camera before the next trace
+
+    // column rays (primary rays with direction.x == +0): slots found whenever directions or bands change
+    static const uint32_t kColumnCap = 1u << 16;
+    DevBuf<uint32_t> d_column_count, d_column_pixels, d_column_flags;
+    DevBuf<unsigned long long> d_column_best;
+    DevBuf<unsigned char> d_reached;
+    bool columns_dirty = true;
+    uint32_t n_columns = 0;              // host copy of the count (read back once per change)
+    uint32_t n_refs = 0;
 
     int n_cus = 0;
     int blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};   // trace-kernel residency per (mode, stats), queried once
@@ -130,6 +141,9 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.accum = c->d_accum.ptr; p.image = c->d_image.ptr;
     p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
     p.counters = c->d_counters.ptr;
+    p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
+    p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
+    p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr;
 }
 
 // Every material index a kernel can read must be in range: the kernels do not check.
@@ -189,7 +203,10 @@ rt_ctx* rt_create(int device_id)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || prop.multiProcessorCount <= 0 ||
         c->d_counters.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * 4) != hipSuccess ||
-        hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess) {
+        hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
+        c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
+        hipMemset(c->d_column_count.ptr, 0, 4) != hipSuccess || hipMemset(c->d_column_flags.ptr, 0, 4) != hipSuccess) {
         fail(nullptr, RT_E_HIP, "device query / counter allocation failed on device %d", device_id);
         rt_destroy(c); return nullptr;
     }
@@ -205,6 +222,7 @@ void rt_destroy(rt_ctx* c)
     c->d_spheres.release(); c->d_materials.release(); c->d_nodes.release(); c->d_leafrecs.release();
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release();
+    c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -239,7 +257,7 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
     HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, n * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_image.ptr, 0, n * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_ids.ptr, 0xFF, n * sizeof(int32_t), c->stream));
-    c->use_host_dirs = false; c->dirs_dirty = true;
+    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true;
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -314,7 +332,7 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     HIP_TRY(c, c->d_trishade.resize(shade.size()));
     HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->n_tris = ntris; c->n_verts = nverts;
-    c->n_nodes = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
+    c->n_nodes = 0; c->n_refs = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
     return RT_OK;
 }
 
@@ -379,7 +397,8 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
                 float tagf; memcpy(&tagf, &tag, 4);
                 recs[3 * next_ref] = make_float4(v0[0], v0[1], v0[2], e1x);
                 recs[3 * next_ref + 1] = make_float4(e1y, e1z, e2x, e2y);
-                recs[3 * next_ref + 2] = make_float4(e2z, tagf, 0.0f, 0.0f);
+                float nodef; memcpy(&nodef, &k, 4);
+                recs[3 * next_ref + 2] = make_float4(e2z, tagf, nodef, 0.0f);
                 ++next_ref;
             }
         }
@@ -394,7 +413,9 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     HIP_TRY(c, c->d_leafrecs.resize(recs.empty() ? 3 : recs.size()));
     HIP_TRY(c, hipMemcpy(c->d_nodes.ptr, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
-    c->n_nodes = M;
+    HIP_TRY(c, c->d_reached.resize(M));
+    HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs;
     return RT_OK;
 }
 
@@ -412,19 +433,20 @@ int rt_set_ray_dirs(rt_ctx* c, const float* xyz, size_t n)
 {
     if (!c) return RT_E_ARG;
     DeviceGuard g(c->device);
-    if (!xyz) { if (c->use_host_dirs) { c->use_host_dirs = false; c->dirs_dirty = true; } return RT_OK; }
+    if (!xyz) { if (c->use_host_dirs) { c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; } return RT_OK; }
     if (!c->width || n != (size_t)c->width * c->height) return fail(c, RT_E_ARG, "rt_set_ray_dirs: %zu directions for a %ux%u frame", n, c->width, c->height);
     std::vector<float4> packed(n);
     for (size_t i = 0; i < n; ++i) packed[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_dirs.ptr, packed.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-    c->use_host_dirs = true; c->dirs_dirty = false;
+    c->use_host_dirs = true; c->dirs_dirty = false; c->columns_dirty = true;
     return RT_OK;
 }
 
 int rt_set_bands(rt_ctx* c, uint32_t band_index, uint32_t band_count)
 {
     if (!c || !band_count || band_index >= band_count) return fail(c, RT_E_ARG, "rt_set_bands(%u, %u)", band_index, band_count);
+    if (band_index != c->band_index || band_count != c->band_count) c->columns_dirty = true;
     c->band_index = band_index; c->band_count = band_count;
     return RT_OK;
 }
@@ -436,7 +458,19 @@ int ensure_dirs(rt_ctx* c, const RtParams& p)
 {
     if (!c->dirs_dirty || c->use_host_dirs) return RT_OK;
     HIP_TRY(c, rt_launch_raygen(&p, c->stream));
-    c->dirs_dirty = false;
+    c->dirs_dirty = false; c->columns_dirty = true;
+    return RT_OK;
+}
+
+// Column rays of the current directions/bands: slots into dirs[].w, count read back once (only when something changed).
+int ensure_columns(rt_ctx* c, const RtParams& p)
+{
+    if (!c->columns_dirty) return RT_OK;
+    HIP_TRY(c, hipMemsetAsync(c->d_column_count.ptr, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->columns_dirty = false;
     return RT_OK;
 }
 
@@ -473,6 +507,11 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
     if (int rc = ensure_dirs(c, p)) return rc;
+    if (mode != RT_SCENE_SPHERES) {
+        if (int rc = ensure_columns(c, p)) return rc;
+        if (c->n_columns) HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
+        else p.column_best = nullptr;
+    } else p.column_best = nullptr;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, p.n_units, grid)) return rc;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;

@@ -26,7 +26,7 @@
 //             vertices pre-gathered so a leaf is one contiguous run:
 //               [0] = { v0.x, v0.y, v0.z, e1.x }   e1 = v1 - v0, e2 = v2 - v0 (the first two operations of
 //               [1] = { e1.y, e1.z, e2.x, e2.y }   Intersections::triIntersect, Intersections.cpp:58-59, done once)
-//               [2] = { e2.z, bits(tri | last<<31), 0, 0 }
+//               [2] = { e2.z, bits(tri | last<<31), bits(node index of the leaf), 0 }
 //  trishade : 3 x float4 per triangle (read once per closest hit): the three corner normals + material
 //               [0] = { n0.x, n0.y, n0.z, n1.x }  [1] = { n1.y, n1.z, n2.x, n2.y }  [2] = { n2.z, bits(material), 0, 0 }
 //  spheres  : float4 { center.xyz, radius*radius } + uint32 material, index order = Scene::spheres order
@@ -59,5 +59,13 @@ struct RtParams {
     float4* image;
     int32_t* primary_ids;                   // optional
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
+    // primary rays with direction.x == +0 ("column rays"): found when directions change, resolved per frame by a pre-pass
+    uint32_t  n_refs;                        // leaf records
+    uint32_t  column_cap;
+    uint32_t* column_count;                  // number of column rays (<= column_cap)
+    uint32_t* column_pixels;                 // their pixel indices; dirs[pixel].w holds slot + 1 (0 = not a column ray)
+    unsigned long long* column_best;         // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
+    uint32_t* column_flags;                  // bit 0: the pre-pass may not be used (some decision depended on t)
+    unsigned char* reached;                  // per node: visited by column rays (pre-pass scratch)
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

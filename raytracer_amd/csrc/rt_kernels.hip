@@ -390,6 +390,7 @@ struct Path {
     F3 O, D, contribution, finalColor;
     unsigned long long rng;
     uint32_t bounce;
+    uint32_t column_slot;          // slot + 1 in the column-ray tables when this pixel's primary ray has direction.x == +0
 };
 
 __device__ __forceinline__ void path_begin(Path& s, const RtParams& p, uint32_t pixel, uint32_t frame)
@@ -401,6 +402,7 @@ __device__ __forceinline__ void path_begin(Path& s, const RtParams& p, uint32_t 
     s.finalColor = f3(0.0f, 0.0f, 0.0f);
     s.rng = pixel_seed(pixel, frame, p.seed);
     s.bounce = 0;
+    s.column_slot = __float_as_uint(d.w);
 }
 
 // One iteration of the bounce loop (Renderer.cpp:149-226).  Returns true when the path has ended (miss, roulette, or the
@@ -517,6 +519,124 @@ __global__ __launch_bounds__(256) void rt_raygen_kernel(RtParams p)
     p.dirs_out[pixel] = make_float4(d.x, d.y, d.z, 0.0f);
 }
 
+// ---- column rays: primary rays with direction.x == +0 (see trace_mesh_cooperative for why they cannot be pruned) ------------
+// They share the origin and, because the NaN of the x slab overrides the other two axes, the same set of visited leaves.
+// rt_column_collect finds them when the directions change; per frame rt_column_reach marks the visited nodes once and
+// rt_column_test tries every record of a visited leaf against every column ray, keeping min (t, record index) per ray.
+__global__ __launch_bounds__(256) void rt_column_collect_kernel(RtParams p)
+{
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    if (pixel >= p.width * p.height) return;
+    const uint32_t y = pixel / p.width;
+    float4 d = p.dirs_out[pixel];
+    uint32_t slot1 = 0;
+    const bool owned = ((y / RT_TILE) % p.band_count) == p.band_index;
+    if (owned && __float_as_uint(d.x) == 0u) {                  // +0 exactly; -0 rays take the in-kernel path
+        const uint32_t slot = atomicAdd(p.column_count, 1u);
+        if (slot < p.column_cap) { p.column_pixels[slot] = pixel; slot1 = slot + 1u; }
+    }
+    d.w = __uint_as_float(slot1);
+    p.dirs_out[pixel] = d;
+}
+
+// One workgroup walks the preorder node array in 1024-node windows for the ray of column slot 0 (any column ray gives the
+// same decisions): reached[node] = 1 for visited nodes whose box counts as hit.  Also clears the per-ray results.
+__global__ __launch_bounds__(1024) void rt_column_reach_kernel(RtParams p, int stats)
+{
+    __shared__ uint32_t wave_max[16];
+    __shared__ uint32_t s_killed_to, s_dependent, s_nodes;
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    if (count == 0u) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (uint32_t i = tid; i < count; i += 1024u) p.column_best[i] = ~0ull;
+    if (tid == 0) { s_killed_to = 0u; s_dependent = 0u; s_nodes = 0u; }
+    const float4 d4 = p.dirs[p.column_pixels[0]];
+    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+    const F3 invD = f3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
+    const uint32_t end = p.n_nodes;
+    uint32_t base = 0, my_nodes = 0;
+    bool dependent = false;
+    __syncthreads();
+    while (base < end) {
+        const uint32_t killed_to = s_killed_to;
+        const uint32_t j = base + tid;
+        const bool valid = j < end;
+        float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+        if (valid) { n0 = p.nodes[2 * (size_t)j]; n1 = p.nodes[2 * (size_t)j + 1]; }
+        float tNear;
+        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const uint32_t kill_end = (valid && !box) ? __float_as_uint(n0.w) : 0u;
+        uint32_t pm = kill_end;                                 // inclusive prefix maximum inside the wave
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(pm, off);
+            if ((int)lane >= off) pm = pm > o ? pm : o;
+        }
+        if (lane == 63u) wave_max[wv] = pm;
+        __syncthreads();
+        uint32_t before = killed_to;                            // maximum over the earlier waves of the window
+        for (uint32_t w = 0; w < wv; ++w) before = before > wave_max[w] ? before : wave_max[w];
+        uint32_t excl = __shfl_up(pm, 1);
+        if (lane == 0u) excl = 0u;
+        const uint32_t limit = excl > before ? excl : before;
+        const bool visited = valid && j >= limit;
+        if (visited) {
+            my_nodes++;
+            if (box && tNear == tNear) dependent = true;
+        }
+        if (valid) p.reached[j] = (visited && box) ? 1 : 0;
+        if (tid == 0) {
+            uint32_t all = killed_to;
+            for (uint32_t w = 0; w < 16u; ++w) all = all > wave_max[w] ? all : wave_max[w];
+            s_killed_to = all;
+        }
+        __syncthreads();
+        base += 1024u;
+        const uint32_t k = s_killed_to;
+        if (k > base) {                                         // nodes up to k lie in a rejected subtree: mark and jump
+            for (uint32_t i = base + tid; i < k && i < end; i += 1024u) p.reached[i] = 0;
+            base = k;
+        }
+        __syncthreads();
+    }
+    if (dependent) s_dependent = 1u;
+    if (stats) atomicAdd(&s_nodes, my_nodes);
+    __syncthreads();
+    if (tid == 0) {
+        *p.column_flags = s_dependent ? 1u : 0u;
+        if (stats && !s_dependent) p.counters[1] += (unsigned long long)s_nodes * count;   // every column ray visits these nodes
+    }
+}
+
+// One lane per leaf record: records of visited leaves are tested against every column ray.
+__global__ __launch_bounds__(256) void rt_column_test_kernel(RtParams p, int stats)
+{
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    if (count == 0u || (*p.column_flags & 1u)) return;
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    bool use = false;
+    float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+    if (r < p.n_refs) {
+        r2 = p.leafrecs[3 * (size_t)r + 2];
+        use = p.reached[__float_as_uint(r2.z)] != 0;
+        if (use) { r0 = p.leafrecs[3 * (size_t)r]; r1 = p.leafrecs[3 * (size_t)r + 1]; }
+    }
+    const unsigned long long any = __ballot(use);
+    if (stats) {
+        const uint32_t n = (uint32_t)__popcll(any);
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.counters[2], (unsigned long long)n * count);
+    }
+    if (any == 0ull) return;
+    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+    for (uint32_t s = 0; s < count; ++s) {
+        const float4 d4 = p.dirs[p.column_pixels[s]];           // wave-uniform
+        float tt, u, v;
+        if (use && tri_test(r0, r1, r2, O, f3(d4.x, d4.y, d4.z), tt, u, v)) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
+            if (key < p.column_best[s]) atomicMin(&p.column_best[s], key);
+        }
+    }
+}
+
 // The trace kernel is persistent: the grid is sized to what the chip holds at once and every wave walks its own list of
 // pixel tiles.  Each loop iteration advances every live lane by one bounce; lanes whose path ended take the next
 // (pixel, frame) before the next iteration, so the wave stays full until its list runs dry.  A lane keeps its pixel for all
@@ -536,7 +656,7 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
     uint32_t pixel = 0, frame = 0;
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
-    s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0;
+    s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
 
     for (;;) {
         // ---- give every idle lane a pixel while this wave has units left
@@ -562,7 +682,20 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
         bool have_mesh_hit = false;
         Hit mesh_hit; mesh_hit.t = FLT_MAX; mesh_hit.id = -1; mesh_hit.u = 0.0f; mesh_hit.v = 0.0f;
         if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) {
-            const bool unprunable = live && s.bounce < p.bounces && s.D.x == 0.0f;
+            bool unprunable = live && s.bounce < p.bounces && s.D.x == 0.0f;
+            // primary column rays were resolved for the whole frame by the pre-pass: re-run the winning triangle test for u, v
+            if (unprunable && s.bounce == 0 && s.column_slot != 0u && p.column_best && (*p.column_flags & 1u) == 0u) {
+                const unsigned long long key = p.column_best[s.column_slot - 1u];
+                if (key != ~0ull) {
+                    const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    float tt, u, v;
+                    tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
+                    mesh_hit.t = tt; mesh_hit.u = u; mesh_hit.v = v; mesh_hit.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
+                }
+                have_mesh_hit = true;
+                unprunable = false;
+            }
             unsigned long long todo = __ballot(unprunable);
             while (todo != 0ull) {
                 const int src = __ffsll((long long)todo) - 1;
@@ -688,6 +821,20 @@ extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s)
 {
     const unsigned n = p->width * p->height;
     hipLaunchKernelGGL(rt_raygen_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s)
+{
+    const unsigned n = p->width * p->height;
+    hipLaunchKernelGGL(rt_column_collect_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s)
+{
+    hipLaunchKernelGGL(rt_column_reach_kernel, dim3(1), dim3(1024), 0, s, *p, stats);
+    hipLaunchKernelGGL(rt_column_test_kernel, dim3((p->n_refs + 255u) / 256u), dim3(256), 0, s, *p, stats);
     return hipGetLastError();
 }
 

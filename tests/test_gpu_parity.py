@@ -457,3 +457,48 @@ def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
         osc.render_frame(st, cam["pos"], cam["dirs"], w, h, fr, o_acc, o_img)
     assert np.array_equal(bits(acc), bits(o_acc))
     assert np.array_equal(bits(img), bits(o_img))
+
+
+# ---- rays with exactly-zero direction components (NaN slab tests) -----------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 2])
+def test_zero_direction_components_all_patterns(rt, orc, renderer, mode):
+    """Host-supplied directions with +0 / -0 planted in x, y, z (alone and combined) on scattered pixels, next to the default
+    camera's own +0 column: the pre-pass (x == +0 primaries), the wave-cooperative walk (x == -0, and any bounce) and the
+    ordinary walk (zeros in y / z only) must all reproduce the reference's visited sets and hits."""
+    from raytracer_amd import scenes
+    w, h = 128, 80
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(28))
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h).copy()
+    rng = np.random.default_rng(5)
+    pick = rng.choice(w * h, 90, replace=False)
+    pz, nz = np.float32(0.0), np.float32(-0.0)
+    for i, px in enumerate(pick):
+        k = i % 9
+        if k == 0: dirs[px, 0] = pz
+        elif k == 1: dirs[px, 0] = nz
+        elif k == 2: dirs[px, 1] = pz
+        elif k == 3: dirs[px, 2] = nz
+        elif k == 4: dirs[px, 0] = pz; dirs[px, 1] = pz
+        elif k == 5: dirs[px, 0] = nz; dirs[px, 2] = pz
+        elif k == 6: dirs[px, 1] = nz; dirs[px, 2] = nz
+        elif k == 7: dirs[px, 0] = pz; dirs[px, 1] = nz; dirs[px, 2] = pz          # a ray going nowhere
+        else: dirs[px, 0] = pz; dirs[px] *= np.float32(3.0)                        # not unit length
+    st = renderer.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, 5, True, False, True, 1337
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(True); renderer.reset_counters()
+    renderer.upload(scene, cam)
+    renderer.set_ray_dirs(dirs)
+    try:
+        acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
+        cnt = orc.Counters()
+        ost = orc.Settings(1, mode, 1, 0, 5)
+        for f in range(1, 4):
+            renderer.Render(scene, cam)
+            osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, primary_ids=ids if f == 1 else None, counters=cnt)
+        got = dict(ids=renderer.read_primary_ids().ravel(), acc=renderer.read_accum().reshape(-1, 3),
+                   img=renderer.GetImage().data.reshape(-1, 4), cnt=renderer.read_counters())
+        # NaN never equals NaN bitwise-safe compare is what bits() does; a ray going nowhere yields NaN radiance in both
+        assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=cnt), ("rays", "nodes_visited", "tris_tested"))
+    finally:
+        renderer.set_ray_dirs(None); renderer.set_stats(False)
