@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the tracing path: Mrays/s (primary + bounce) and ms/frame.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|3|4|5]
 
 A step is one Renderer::Render (one 1-spp frame) of the configured scene.  Default workload = BASELINE.json configs[1]:
 the reference application's default sphere scene at 1920x1080, 5 bounces, 64 accumulated frames.  With N > 1 (launched
@@ -39,6 +39,10 @@ CONFIGS = {
     2: dict(name="default sphere scene 1920x1080, 5 bounces, 64 spp (BASELINE configs[1])", w=1920, h=1080, bounces=5, mode=1, mesh=None),
     3: dict(name="69,938-triangle displaced grid + KD tree, 1920x1080, 8 bounces (BASELINE configs[2])", w=1920, h=1080,
             bounces=8, mode=0, mesh=("grid", 187)),
+    4: dict(name="9,999,392-triangle displaced grid + KD tree in HBM, 3840x2160, 8 bounces, screen-tile split (BASELINE configs[3])",
+            w=3840, h=2160, bounces=8, mode=0, mesh=("grid", 2236), split="tile"),
+    5: dict(name="default spheres + 9,999,392-triangle mesh, 3840x2160, 8 bounces, progressive, sample split (BASELINE configs[4])",
+            w=3840, h=2160, bounces=8, mode=2, mesh=("grid", 2236)),
 }
 
 
@@ -65,7 +69,7 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
     threads = max(1, min(16, os.cpu_count() or 1))
     oscene = orc.Scene()
     oscene.set_spheres(scene.spheres); oscene.set_materials(scene.materials)
-    row_step = 1
+    row_step = 64 if (cfg["mesh"] and cfg["mesh"][1] > 1000) else 1
     if scene.kd_tree is not None:
         oscene.set_mesh(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat)
         oscene.import_kd(scene.kd_tree.arrays())
@@ -80,7 +84,7 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
     return {"value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "%d frame(s) of the same %dx%d workload%s, oracle (CPU restatement, hash RNG), %.1f s wall"
                       % (budget_frames, w, h, "" if row_step == 1 else ", every %dth row" % row_step, dt),
-            "ms_per_frame": dt / budget_frames * 1e3 * (1 if row_step == 1 else row_step)}
+            "ms_per_frame_extrapolated": dt / budget_frames * 1e3 * row_step}
 
 
 def main():
@@ -136,15 +140,25 @@ def main():
         if use_dist:
             dist.barrier()
 
-    # frame indices of this rank: sample split (world == 1: 1, 2, 3, ...)
-    warm = rtd.frames_for_rank(rank, world, W)
-    frames = rtd.frames_for_rank(rank, world, K, first=1)
-    acc_t = rtd.accum_tensor(r) if use_dist else None
+    tile_split = cfg.get("split") == "tile"
+    if tile_split:
+        # screen-tile split: every rank renders all K frames of its own 16-row bands; bands are gathered on rank 0 per frame
+        r.set_bands(rank, world)
+        warm = list(range(1, W + 1)); frames = list(range(1, K + 1))
+        img_t = rtd.image_tensor(r) if use_dist else None
+        acc_t = None
+    else:
+        # sample split: rank r renders frame indices r+1, r+1+N, ... (world == 1: 1, 2, 3, ...)
+        warm = rtd.frames_for_rank(rank, world, W)
+        frames = rtd.frames_for_rank(rank, world, K, first=1)
+        acc_t = rtd.accum_tensor(r) if use_dist else None
 
     r.reset_accum()
     for f in warm:
         r.render_only(f + 1000)                      # warmup only heats caches/clocks; its sum is discarded
-    if use_dist:
+        if tile_split and use_dist:
+            rtd.gather_bands(img_t, rank, world)
+    if use_dist and not tile_split:
         rtd.sum_accumulation(acc_t)
     r.sync(); torch.cuda.synchronize(); barrier()
     r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
@@ -153,7 +167,9 @@ def main():
     t0 = time.perf_counter()
     for f in frames:                                 # every rank starts from a zeroed buffer (rt_reset_accum)
         r.render_only(f)
-    if use_dist:
+        if tile_split and use_dist:
+            rtd.gather_bands(img_t, rank, world)     # the displayed frame, assembled on rank 0
+    if use_dist and not tile_split:
         rtd.sum_accumulation(acc_t)
         if rank == 0:
             r.resolve(world * K)
@@ -193,22 +209,29 @@ def main():
                       + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
             achieved = bytes_ / avg_kernel_s / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": _traffic_from_profile(args.config), "kernel": "rt_trace_kernel<mesh>",
+                    "traffic": _traffic_from_profile(args.config),
+                    "kernel": "rt_column_reach_kernel + rt_column_test_kernel + rt_trace_kernel<%s> (one event pair around the three)"
+                              % ("mesh" if cfg["mode"] == 0 else "both"),
                     "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
                     "nodes_per_ray": c2.nodes_visited / max(c2.rays, 1), "tris_per_ray": c2.tris_tested / max(c2.rays, 1),
                     "rays_per_launch": rays_per_launch,
-                    "note": "tree + triangles fit the 256 MiB Infinity Cache at this size: traffic is cache traffic, not HBM"}
+                    "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested (+40 B per hit, +40 B per pixel) "
+                            "with the reference traversal's own visit counts (device counters == oracle counters); "
+                            + ("tree + leaf records (20 MB) sit in L2 / Infinity Cache at this size, so this is cache traffic, not HBM"
+                               if cfg["mesh"][1] < 1000 else "tree + leaf records are ~2.7 GB: HBM-resident random access")}
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if tile_split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["name"], "width": w, "height": h, "bounces": cfg["bounces"],
-                       "frames_per_gpu": K, "split": "sample" if use_dist else "none",
-                       "rays_per_frame": rays_total / (K * world), "image": "resident in HBM (no D2H in the timed region)"},
+                       "frames_per_gpu": K, "split": ("tile" if tile_split else "sample") if use_dist else "none",
+                       "rays_per_frame": rays_total / (K if tile_split else K * world), "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
         if not args.no_cpu_baseline:
             n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work
+            if cfg["mesh"] and cfg["mesh"][1] > 1000:
+                n = 1                                                    # 10 M triangles at 4K: one frame of every 64th row
             out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
         print(json.dumps(out), flush=True)
 

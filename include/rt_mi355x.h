@@ -72,7 +72,8 @@ typedef struct {
    maintained while rt_set_stats(ctx, 1). */
 typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests; } rt_counters;
 
-/* Device time of the dominant kernel, measured with HIP events on the stream it was launched on. */
+/* Device time of the tracing kernels of a frame (the trace kernel, preceded for mesh scenes by the column pre-pass),
+   measured with HIP events on the stream they were launched on. */
 typedef struct { uint64_t launches; double total_ms; double last_ms; } rt_kernel_time;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */

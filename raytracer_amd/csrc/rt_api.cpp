@@ -507,15 +507,15 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
     if (int rc = ensure_dirs(c, p)) return rc;
-    if (mode != RT_SCENE_SPHERES) {
-        if (int rc = ensure_columns(c, p)) return rc;
-        if (c->n_columns) HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
-        else p.column_best = nullptr;
-    } else p.column_best = nullptr;
+    if (mode != RT_SCENE_SPHERES) { if (int rc = ensure_columns(c, p)) return rc; }
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, p.n_units, grid)) return rc;
+    // the event pair brackets the tracing kernels of the frame: the column pre-pass (mesh scenes whose camera has
+    // direction.x == +0 pixels) and the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
+    if (mode != RT_SCENE_SPHERES && c->n_columns) HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
+    else p.column_best = nullptr;
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
