@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--order", default="auto", choices=["auto", "reference", "front-to-back"],
+                    help="KD tree walk order of mesh scenes (auto = front to back on a KD tree)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +132,7 @@ def main():
     r.download = False                               # frames stay in HBM; the host copy is priced separately
     st = r.GetSettings()
     st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
+    st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]
     r.OnResize(w, h)
     stream = torch.cuda.Stream()                     # one stream for the kernels and the collective that follows them
     torch.cuda.set_stream(stream)
@@ -203,7 +206,18 @@ def main():
             r.set_stats(True); r.reset_accum(); r.reset_counters()
             for f in frames:
                 r.render_only(f)
-            c2 = r.read_counters(); r.set_stats(False)
+            c2 = r.read_counters()
+            order_used = "front-to-back" if r.traversal_in_use() == 2 else "reference"
+            ref_counts = None
+            if order_used != "reference":                # what the reference's own walk order costs on the same rays
+                st.TraversalOrder = 1; r.push_settings()
+                r.reset_accum(); r.reset_counters()
+                for f in frames[:4]:
+                    r.render_only(f)
+                c3 = r.read_counters()
+                ref_counts = {"nodes_per_ray": c3.nodes_visited / max(c3.rays, 1), "tris_per_ray": c3.tris_tested / max(c3.rays, 1)}
+                st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
+            r.set_stats(False)
             per_launch = lambda v: v / max(len(frames), 1)
             bytes_ = (per_launch(c2.nodes_visited) * BYTES_PER_NODE + per_launch(c2.tris_tested) * BYTES_PER_TRI
                       + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
@@ -214,9 +228,9 @@ def main():
                               % ("mesh" if cfg["mode"] == 0 else "both"),
                     "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
                     "nodes_per_ray": c2.nodes_visited / max(c2.rays, 1), "tris_per_ray": c2.tris_tested / max(c2.rays, 1),
-                    "rays_per_launch": rays_per_launch,
+                    "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
                     "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested (+40 B per hit, +40 B per pixel) "
-                            "with the reference traversal's own visit counts (device counters == oracle counters); "
+                            "with the node / triangle counts of the walk order that was timed (device counters); "
                             + ("tree + leaf records (20 MB) sit in L2 / Infinity Cache at this size, so this is cache traffic, not HBM"
                                if cfg["mesh"][1] < 1000 else "tree + leaf records are ~2.7 GB: HBM-resident random access")}
         out = {

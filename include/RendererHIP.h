@@ -75,6 +75,7 @@ public:
         bool UseACE_Color = true;
         bool AntiAliasing = false;
         uint32_t Bounces = 8;
+        int TraversalOrder = RT_ORDER_AUTO;    // not in the reference: KD tree walk order, see rt_mi355x.h
     };
     Settings& GetSettings() { return m_settings; }
 
@@ -106,7 +107,7 @@ public:
         rt_settings st;
         st.accumulate = m_settings.Accumulate; st.scene_mode = m_settings.UseSphereScene ? RT_SCENE_SPHERES : RT_SCENE_MESH;
         st.use_ace = m_settings.UseACE_Color; st.anti_aliasing = m_settings.AntiAliasing;
-        st.bounces = m_settings.Bounces; st.seed = 1337;
+        st.bounces = m_settings.Bounces; st.seed = 1337; st.traversal = m_settings.TraversalOrder;
         check(rt_set_settings(m_ctx, &st), "rt_set_settings");
 
         // spheres and materials are edited live by the UI (RaytracerApp.cpp:283-331): sent every frame (a few hundred bytes)

@@ -40,7 +40,8 @@ typedef struct { float albedo[3]; float emission[3]; float roughness, transparen
 /* Renderer::Settings (RayTracer/src/Renderer.h:103-110) as plain ints.  `scene_mode` carries UseSphereScene
    (0 = mesh through the KD tree, 1 = spheres) and adds 2 = both, nearest wins by the strict sphere-first compare
    of Renderer.cpp:292-300.  `seed` seeds the per-(pixel, frame) pcg32 streams (the value Walnut::Random::Init
-   intended, Random.h:22, is 1337). */
+   intended, Random.h:22, is 1337).  `traversal` (no counterpart in the reference) selects the order in which the KD
+   tree is walked, see RT_ORDER_*. */
 typedef struct {
     int32_t  accumulate;
     int32_t  scene_mode;
@@ -48,9 +49,25 @@ typedef struct {
     int32_t  anti_aliasing;
     uint32_t bounces;
     uint32_t seed;
+    int32_t  traversal;
 } rt_settings;
 
 enum { RT_SCENE_MESH = 0, RT_SCENE_SPHERES = 1, RT_SCENE_BOTH = 2 };
+
+/* Tree walk order.
+   RT_ORDER_REFERENCE: exactly KDTreeCPU::intersect (KDAccel/KDTreeCPU.cpp:649-708): box test, left subtree, right
+     subtree, a subtree skipped when its box's t_near exceeds the closest t so far.  Same visited nodes and tested
+     triangles as the reference, ray by ray (the nodes_visited / tris_tested counters equal the reference's).
+   RT_ORDER_FRONT_TO_BACK: the same box and triangle tests and the same pruning rule, but at every node the child on
+     the ray's near side is walked first (eight node arrays in HBM, one per sign pattern of the ray direction, so the
+     walk stays a stackless "next node or skip link" loop).  Result = the smallest t over the leaves whose chain of
+     boxes the ray hits, equal t resolved to the triangle the reference order reaches first.  That is the reference's
+     result whenever every triangle is listed in each leaf whose box it overlaps (the reference builder,
+     KDTreeCPU.cpp:548-597, guarantees it); the two orders can only differ when two different triangles are hit
+     within rounding distance of each other exactly on a leaf boundary.  Far fewer nodes and triangles per ray.
+   RT_ORDER_AUTO (default): front to back when the uploaded tree's two-child nodes split their box in two along one
+     axis (a KD tree, as the reference builds), otherwise the reference order. */
+enum { RT_ORDER_AUTO = 0, RT_ORDER_REFERENCE = 1, RT_ORDER_FRONT_TO_BACK = 2 };
 
 /* Host KD tree flattened for upload: what a walk of KDTreeCPU::getRootNode() (KDAccel/KDTreeCPU.cpp:73-76,
    node fields KDAccel/KDTreeStructs.h:55-76) emits.  Children are node indices, -1 = none (a node may have
@@ -98,6 +115,9 @@ int rt_set_mesh(rt_ctx*, const float* verts, uint32_t nverts, const uint32_t* tr
                 const float* normals9, const uint32_t* tri_mat, uint32_t ntris);
 /* Scene::kd_tree (Scene.h:43): the flattened host tree; requires rt_set_mesh first. */
 int rt_set_kdtree(rt_ctx*, const rt_kd_flat*);
+/* The order the next mesh frame will be walked in under the current settings and tree: RT_ORDER_REFERENCE or
+   RT_ORDER_FRONT_TO_BACK (resolves RT_ORDER_AUTO). */
+int rt_traversal_in_use(const rt_ctx*);
 /* Camera::GetPosition / GetInverseProjection / GetInverseView (Camera.h:15-19), column-major like glm::mat4;
    ray directions are generated on the device exactly as Camera::RecalculateRayDirections (Camera.cpp:134-150). */
 int rt_set_camera(rt_ctx*, const float pos[3], const float inv_proj[16], const float inv_view[16]);

@@ -12,12 +12,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
 
 RT_OK = 0
 SCENE_MESH, SCENE_SPHERES, SCENE_BOTH = 0, 1, 2
+ORDER_AUTO, ORDER_REFERENCE, ORDER_FRONT_TO_BACK = 0, 1, 2
 ID_TRI_BIT = 0x40000000
 
 # every symbol include/rt_mi355x.h declares
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_settings", "rt_set_spheres",
-    "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
+    "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_traversal_in_use", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
     "rt_render_frames", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_read_accum", "rt_set_record_ids",
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_device_accum", "rt_device_image",
@@ -27,7 +28,7 @@ EXPORTS = [
 
 class RtSettings(C.Structure):
     _fields_ = [("accumulate", C.c_int32), ("scene_mode", C.c_int32), ("use_ace", C.c_int32),
-                ("anti_aliasing", C.c_int32), ("bounces", C.c_uint32), ("seed", C.c_uint32)]
+                ("anti_aliasing", C.c_int32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_int32)]
 
 
 class RtKdFlat(C.Structure):
@@ -82,7 +83,7 @@ def lib():
         "rt_set_stream": ([vp, vp], C.c_int), "rt_resize": ([vp, u32, u32], C.c_int),
         "rt_set_settings": ([vp, vp], C.c_int), "rt_set_spheres": ([vp, vp, u32], C.c_int),
         "rt_set_materials": ([vp, vp, u32], C.c_int), "rt_set_mesh": ([vp, vp, u32, vp, vp, vp, u32], C.c_int),
-        "rt_set_kdtree": ([vp, vp], C.c_int), "rt_set_camera": ([vp, vp, vp, vp], C.c_int),
+        "rt_set_kdtree": ([vp, vp], C.c_int), "rt_traversal_in_use": ([vp], C.c_int), "rt_set_camera": ([vp, vp, vp, vp], C.c_int),
         "rt_set_ray_dirs": ([vp, vp, sz], C.c_int), "rt_set_bands": ([vp, u32, u32], C.c_int),
         "rt_render": ([vp, u32], C.c_int), "rt_render_frames": ([vp, u32, u32], C.c_int),
         "rt_resolve": ([vp, u32], C.c_int), "rt_reset_accum": ([vp], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int),

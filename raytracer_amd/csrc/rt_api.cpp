@@ -14,8 +14,8 @@
 #include "../../include/rt_mi355x.h"
 #include "rt_device.h"
 
-extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned grid, hipStream_t s);
-extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int* blocks_per_cu);
+extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, int ordered, unsigned grid, hipStream_t s);
+extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* blocks_per_cu);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
@@ -55,7 +55,7 @@ struct rt_ctx {
     std::string error;
 
     uint32_t width = 0, height = 0;
-    rt_settings settings{1, RT_SCENE_MESH, 1, 0, 8, 1337};    // Renderer::Settings defaults (Renderer.h:103-110)
+    rt_settings settings{1, RT_SCENE_MESH, 1, 0, 8, 1337, RT_ORDER_AUTO};    // Renderer::Settings defaults (Renderer.h:103-110)
     bool have_camera = false;
     float cam_pos[3]{}, inv_proj[16]{}, inv_view[16]{};
     uint32_t band_index = 0, band_count = 1;
@@ -84,7 +84,8 @@ struct rt_ctx {
     uint32_t n_refs = 0;
 
     int n_cus = 0;
-    int blocks_per_cu[6] = {0, 0, 0, 0, 0, 0};   // trace-kernel residency per (mode, stats), queried once
+    int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
+    bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
     rt_kernel_time ktime{0, 0.0, 0.0};
 };
@@ -266,6 +267,7 @@ int rt_set_settings(rt_ctx* c, const rt_settings* s)
 {
     if (!c || !s) return RT_E_ARG;
     if (s->scene_mode < 0 || s->scene_mode > 2) return fail(c, RT_E_ARG, "scene_mode %d", s->scene_mode);
+    if (s->traversal < RT_ORDER_AUTO || s->traversal > RT_ORDER_FRONT_TO_BACK) return fail(c, RT_E_ARG, "traversal %d", s->traversal);
     c->settings = *s;
     return RT_OK;
 }
@@ -375,48 +377,114 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     }
     if (n_refs >= 0x7FFFFFFFull / 3) return fail(c, RT_E_LIMIT, "rt_set_kdtree: %zu leaf references exceed the index space", n_refs);
 
-    std::vector<float4> nodes(2 * (size_t)M), recs(3 * n_refs);
+    // Leaf records in the reference's visit order (preorder, left first); a leaf's first record by original node id.
+    std::vector<float4> recs(3 * n_refs);
+    std::vector<int32_t> leaf_first_of(N, RT_LEAF_INTERIOR);
     size_t next_ref = 0;
     for (uint32_t k = 0; k < M; ++k) {
         uint32_t n = order[k];
-        uint32_t skip = k + subtree[k];
-        int32_t leaf_first = RT_LEAF_INTERIOR;
-        if (kd->left[n] < 0 && kd->right[n] < 0) {
-            leaf_first = kd->count[n] > 0 ? (int32_t)next_ref : RT_LEAF_EMPTY;
-            for (int32_t i = 0; i < kd->count[n]; ++i) {
-                int32_t tri = kd->leaf_idx[kd->first[n] + i];
-                if (tri < 0 || (uint32_t)tri >= c->n_tris) return fail(c, RT_E_ARG, "rt_set_kdtree: triangle index %d out of range in leaf %u", tri, n);
-                const uint32_t* ix = &c->h_tris[3 * (size_t)tri];
-                const float* v0 = &c->h_verts[3 * (size_t)ix[0]];
-                const float* v1 = &c->h_verts[3 * (size_t)ix[1]];
-                const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
-                // e1 = v1 - v0, e2 = v2 - v0: the first two operations of triIntersect (Intersections.cpp:58-59)
-                volatile float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
-                volatile float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
-                uint32_t tag = (uint32_t)tri | ((i == kd->count[n] - 1) ? 0x80000000u : 0u);
-                float tagf; memcpy(&tagf, &tag, 4);
-                recs[3 * next_ref] = make_float4(v0[0], v0[1], v0[2], e1x);
-                recs[3 * next_ref + 1] = make_float4(e1y, e1z, e2x, e2y);
-                float nodef; memcpy(&nodef, &k, 4);
-                recs[3 * next_ref + 2] = make_float4(e2z, tagf, nodef, 0.0f);
-                ++next_ref;
-            }
+        if (kd->left[n] >= 0 || kd->right[n] >= 0) continue;
+        leaf_first_of[n] = kd->count[n] > 0 ? (int32_t)next_ref : RT_LEAF_EMPTY;
+        for (int32_t i = 0; i < kd->count[n]; ++i) {
+            int32_t tri = kd->leaf_idx[kd->first[n] + i];
+            if (tri < 0 || (uint32_t)tri >= c->n_tris) return fail(c, RT_E_ARG, "rt_set_kdtree: triangle index %d out of range in leaf %u", tri, n);
+            const uint32_t* ix = &c->h_tris[3 * (size_t)tri];
+            const float* v0 = &c->h_verts[3 * (size_t)ix[0]];
+            const float* v1 = &c->h_verts[3 * (size_t)ix[1]];
+            const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
+            // e1 = v1 - v0, e2 = v2 - v0: the first two operations of triIntersect (Intersections.cpp:58-59)
+            volatile float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+            volatile float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+            uint32_t tag = (uint32_t)tri | ((i == kd->count[n] - 1) ? 0x80000000u : 0u);
+            float tagf; memcpy(&tagf, &tag, 4);
+            recs[3 * next_ref] = make_float4(v0[0], v0[1], v0[2], e1x);
+            recs[3 * next_ref + 1] = make_float4(e1y, e1z, e2x, e2y);
+            float nodef; memcpy(&nodef, &k, 4);
+            recs[3 * next_ref + 2] = make_float4(e2z, tagf, nodef, 0.0f);
+            ++next_ref;
         }
-        float skipf, leaff; memcpy(&skipf, &skip, 4); memcpy(&leaff, &leaf_first, 4);
-        nodes[2 * (size_t)k] = make_float4(kd->center[3 * (size_t)n], kd->center[3 * (size_t)n + 1], kd->center[3 * (size_t)n + 2], skipf);
-        nodes[2 * (size_t)k + 1] = make_float4(kd->extent[3 * (size_t)n], kd->extent[3 * (size_t)n + 1], kd->extent[3 * (size_t)n + 2], leaff);
+    }
+
+    // Per two-child node: the axis along which its children are separated and which child is the low one; whether the
+    // tree is a KD tree (each two-child node's children are its own box cut in two along that axis).
+    std::vector<uint8_t> sep_axis(N, 3), low_is_left(N, 1);
+    bool partition = true;
+    for (uint32_t k = 0; k < M; ++k) {
+        const uint32_t n = order[k];
+        const int32_t l = kd->left[n], r = kd->right[n];
+        if (l < 0 || r < 0) continue;
+        const float* cn = &kd->center[3 * (size_t)n]; const float* en = &kd->extent[3 * (size_t)n];
+        const float* cl = &kd->center[3 * (size_t)l]; const float* el = &kd->extent[3 * (size_t)l];
+        const float* cr = &kd->center[3 * (size_t)r]; const float* er = &kd->extent[3 * (size_t)r];
+        int axis = 3; float best = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float d = cl[a] < cr[a] ? cr[a] - cl[a] : cl[a] - cr[a];
+            if (d > best) { best = d; axis = a; }
+        }
+        sep_axis[n] = (uint8_t)axis;
+        if (axis == 3) continue;                                   // coincident boxes (a flat node): any order will do
+        low_is_left[n] = cl[axis] <= cr[axis] ? 1 : 0;
+        const float* clo = low_is_left[n] ? cl : cr; const float* elo = low_is_left[n] ? el : er;
+        const float* chi = low_is_left[n] ? cr : cl; const float* ehi = low_is_left[n] ? er : el;
+        for (int a = 0; a < 3 && partition; ++a) {
+            if (a != axis) { partition = cl[a] == cn[a] && cr[a] == cn[a] && el[a] == en[a] && er[a] == en[a]; continue; }
+            const float tol = 1e-4f * en[a] + 1e-30f;
+            const float lo = cn[a] - en[a], hi = cn[a] + en[a];
+            auto near = [tol](float x, float y) { return (x < y ? y - x : x - y) <= tol; };
+            partition = near(clo[a] - elo[a], lo) && near(chi[a] + ehi[a], hi) && near(clo[a] + elo[a], chi[a] - ehi[a]);
+        }
     }
 
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_nodes.resize(nodes.size()));
+    HIP_TRY(c, c->d_nodes.resize(8 * 2 * (size_t)M));
     HIP_TRY(c, c->d_leafrecs.resize(recs.empty() ? 3 : recs.size()));
-    HIP_TRY(c, hipMemcpy(c->d_nodes.ptr, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+
+    // Eight node arrays, one per sign pattern of a ray direction (bit a set: direction[a] < 0).  Array o is the tree in the
+    // preorder that walks, at every two-child node, the child on the side a ray of that pattern comes from first.  Array 0
+    // is always left-first: it is the reference's own order (RT_ORDER_REFERENCE, the column pre-pass and the cooperative
+    // walk use it), and for a tree of the reference builder the left child is the low one, which is what pattern 0 wants.
+    std::vector<float4> nodes(2 * (size_t)M);
+    std::vector<uint32_t> walk; walk.reserve(M);
+    std::vector<uint32_t> subtree_of(N, 0);
+    for (uint32_t k = 0; k < M; ++k) subtree_of[order[k]] = subtree[k];
+    for (uint32_t o = 0; o < 8; ++o) {
+        walk.clear(); stack.clear(); stack.push_back(0);
+        uint32_t k = 0;
+        while (!stack.empty()) {
+            const uint32_t n = stack.back(); stack.pop_back();
+            const int32_t l = kd->left[n], r = kd->right[n];
+            const uint32_t skip = k + subtree_of[n];
+            const int32_t leaf_first = leaf_first_of[n];
+            float skipf, leaff; memcpy(&skipf, &skip, 4); memcpy(&leaff, &leaf_first, 4);
+            nodes[2 * (size_t)k] = make_float4(kd->center[3 * (size_t)n], kd->center[3 * (size_t)n + 1], kd->center[3 * (size_t)n + 2], skipf);
+            nodes[2 * (size_t)k + 1] = make_float4(kd->extent[3 * (size_t)n], kd->extent[3 * (size_t)n + 1], kd->extent[3 * (size_t)n + 2], leaff);
+            ++k;
+            if (l >= 0 && r >= 0) {
+                bool left_first = true;
+                if (o != 0 && sep_axis[n] != 3) {
+                    const bool from_high = (o >> sep_axis[n]) & 1u;            // the ray travels towards lower coordinates
+                    left_first = from_high ? !low_is_left[n] : (bool)low_is_left[n];
+                }
+                if (left_first) { stack.push_back((uint32_t)r); stack.push_back((uint32_t)l); }
+                else            { stack.push_back((uint32_t)l); stack.push_back((uint32_t)r); }
+            } else if (l >= 0) stack.push_back((uint32_t)l);
+            else if (r >= 0) stack.push_back((uint32_t)r);
+        }
+        HIP_TRY(c, hipMemcpy(c->d_nodes.ptr + (size_t)o * 2 * M, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    }
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, c->d_reached.resize(M));
     HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
-    c->n_nodes = M; c->n_refs = (uint32_t)n_refs;
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition;
     return RT_OK;
+}
+
+int rt_traversal_in_use(const rt_ctx* c)
+{
+    if (!c) return RT_E_ARG;
+    const bool ordered = c->settings.traversal == RT_ORDER_FRONT_TO_BACK || (c->settings.traversal == RT_ORDER_AUTO && c->kd_partition);
+    return ordered ? RT_ORDER_FRONT_TO_BACK : RT_ORDER_REFERENCE;
 }
 
 int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const float inv_view[16])
@@ -475,12 +543,12 @@ int ensure_columns(rt_ctx* c, const RtParams& p)
 }
 
 // Workgroups of the persistent trace grid: what the chip holds at once, but no more than there are tiles to hand out.
-int trace_grid(rt_ctx* c, int mode, bool stats, uint32_t n_units, unsigned& grid)
+int trace_grid(rt_ctx* c, int mode, bool stats, bool ordered, uint32_t n_units, unsigned& grid)
 {
-    int& per_cu = c->blocks_per_cu[mode * 2 + (stats ? 1 : 0)];
+    int& per_cu = c->blocks_per_cu[(mode * 2 + (stats ? 1 : 0)) * 2 + (ordered ? 1 : 0)];
     if (per_cu == 0) {
         int q = 0;
-        HIP_TRY(c, rt_trace_occupancy(mode, stats ? 1 : 0, &q));
+        HIP_TRY(c, rt_trace_occupancy(mode, stats ? 1 : 0, ordered ? 1 : 0, &q));
         per_cu = q < 1 ? 1 : (q > (int)kMaxBlocksPerCu ? (int)kMaxBlocksPerCu : q);
     }
     grid = (unsigned)c->n_cus * (unsigned)per_cu;
@@ -508,15 +576,16 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
     if (int rc = ensure_dirs(c, p)) return rc;
     if (mode != RT_SCENE_SPHERES) { if (int rc = ensure_columns(c, p)) return rc; }
+    const bool ordered = mode != RT_SCENE_SPHERES && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     unsigned grid;
-    if (int rc = trace_grid(c, mode, c->stats, p.n_units, grid)) return rc;
+    if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units, grid)) return rc;
     // the event pair brackets the tracing kernels of the frame: the column pre-pass (mesh scenes whose camera has
     // direction.x == +0 pixels) and the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     if (mode != RT_SCENE_SPHERES && c->n_columns) HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
     else p.column_best = nullptr;
-    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, grid, c->stream));
+    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
     HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));

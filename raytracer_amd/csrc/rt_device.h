@@ -17,11 +17,13 @@
 
 // HBM layouts (all 16-byte aligned, read with dwordx4 loads):
 //
-//  nodes    : 2 x float4 per node, nodes in PREORDER (left subtree before right subtree), so the traversal order
-//             of KDTreeCPU::intersect (KDAccel/KDTreeCPU.cpp:649-708: box test, then left, then right) is
-//             "next node = i + 1 on descend, skip[i] otherwise" with no per-lane stack:
+//  nodes    : 8 arrays of 2 x float4 per node.  Array 0 holds the nodes in PREORDER (left subtree before right subtree),
+//             so the traversal order of KDTreeCPU::intersect (KDAccel/KDTreeCPU.cpp:649-708: box test, then left, then
+//             right) is "next node = i + 1 on descend, skip[i] otherwise" with no per-lane stack:
 //               [0] = { center.x, center.y, center.z, bits(skip) }       skip = index after this node's subtree
 //               [1] = { extent.x, extent.y, extent.z, bits(leaf_first) } first leaf record, or RT_LEAF_*
+//             Array o (bit a of o set = direction[a] < 0) holds the same nodes in the preorder that puts the child on
+//             the near side of such a ray first, with skip links of its own; leaf_first is the same in all arrays.
 //  leafrecs : 3 x float4 per (leaf, triangle) reference, leaves in preorder, triangles in the leaf's own order,
 //             vertices pre-gathered so a leaf is one contiguous run:
 //               [0] = { v0.x, v0.y, v0.z, e1.x }   e1 = v1 - v0, e2 = v2 - v0 (the first two operations of

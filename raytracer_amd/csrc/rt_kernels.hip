@@ -259,40 +259,58 @@ __device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, 
     return ok && (tt > 0.00001f);
 }
 
-template <bool STATS>
+// ORDERED = false: the walk of KDTreeCPU::intersect itself (node array 0 is the reference's preorder).
+// ORDERED = true : node array number (direction.x < 0) + 2 (direction.y < 0) + 4 (direction.z < 0) holds the same tree in
+// the preorder that puts, at every node, the child on the near side of this ray first; boxes, triangle tests and the
+// pruning rule are unchanged, so once a hit is known almost everything behind it is pruned.  Equal t is resolved to the
+// smaller leaf-record index, i.e. to the triangle the reference order reaches first.
+// Both forms alternate between "walk nodes until a leaf is reached" and "test that leaf's triangles", so that the lanes
+// of a wave spend their iterations in the same kind of work.
+template <bool STATS, bool ORDERED>
 __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 invD, Hit& hit, uint32_t& n_nodes_visited,
                                            uint32_t& n_tris_tested)
 {
     float t = FLT_MAX;
     int32_t tri = -1;
     float hu = 0.0f, hv = 0.0f;
+    uint32_t best_rec = 0xFFFFFFFFu;
+    const float4* nodes = p.nodes;
+    if (ORDERED) {
+        const uint32_t octant = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
+        nodes += (size_t)octant * 2u * (size_t)p.n_nodes;
+    }
     uint32_t node = 0;
     const uint32_t end = p.n_nodes;
-    while (node < end) {
-        const float4 n0 = p.nodes[2 * node];
-        const float4 n1 = p.nodes[2 * node + 1];
-        if (STATS) n_nodes_visited++;
-        float tNear;
-        const bool box = slab_test(n0, n1, O, invD, tNear);
-        // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
-        const bool descend = box && !(tNear > t);
-        const uint32_t skip = __float_as_uint(n0.w);
-        const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
-        if (!descend) { node = skip; continue; }
-        if (leaf_first == RT_LEAF_INTERIOR) { node = node + 1; continue; }
-        if (leaf_first >= 0) {
-            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
-            for (;;) {
-                const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                rec += 3;
-                if (STATS) n_tris_tested++;
-                const uint32_t tag = __float_as_uint(r2.y);
-                float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; }
-                if (tag & 0x80000000u) break;
-            }
+    for (;;) {
+        int32_t leaf = -1;
+        while (node < end) {
+            const float4 n0 = nodes[2 * (size_t)node];
+            const float4 n1 = nodes[2 * (size_t)node + 1];
+            if (STATS) n_nodes_visited++;
+            float tNear;
+            const bool box = slab_test(n0, n1, O, invD, tNear);
+            // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
+            const bool descend = box && !(tNear > t);
+            const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+            if (descend && leaf_first == RT_LEAF_INTERIOR) { node = node + 1; continue; }
+            node = __float_as_uint(n0.w);                   // skip link: first node after this subtree
+            if (descend && leaf_first >= 0) { leaf = leaf_first; break; }
         }
-        node = skip;
+        if (leaf < 0) break;
+        uint32_t rec_index = (uint32_t)leaf;
+        const float4* rec = p.leafrecs + 3 * (size_t)leaf;
+        for (;;) {
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            rec += 3;
+            if (STATS) n_tris_tested++;
+            const uint32_t tag = __float_as_uint(r2.y);
+            float tt, u, v;
+            if (tri_test(r0, r1, r2, O, D, tt, u, v) && (tt < t || (ORDERED && tt == t && rec_index < best_rec))) {
+                t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; best_rec = rec_index;
+            }
+            ++rec_index;
+            if (tag & 0x80000000u) break;
+        }
     }
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
 }
@@ -407,7 +425,7 @@ __device__ __forceinline__ void path_begin(Path& s, const RtParams& p, uint32_t 
 
 // One iteration of the bounce loop (Renderer.cpp:149-226).  Returns true when the path has ended (miss, roulette, or the
 // bounce budget is used up).
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool ORDERED>
 __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* primary_id, bool have_mesh_hit, Hit mesh_hit,
                                           uint32_t& n_rays, uint32_t& n_nodes, uint32_t& n_tris)
 {
@@ -426,7 +444,7 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* p
         if (have_mesh_hit) th = mesh_hit;                   // found by the whole wave (zero direction component)
         else {
             F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);  // Renderer.cpp:151
-            trace_mesh<STATS>(p, O, D, invD, th, n_nodes, n_tris);
+            trace_mesh<STATS, ORDERED>(p, O, D, invD, th, n_nodes, n_tris);
         }
     }
 
@@ -643,7 +661,7 @@ __global__ __launch_bounds__(256) void rt_column_test_kernel(RtParams p, int sta
 // n_frames frames and adds them in frame order, which makes the sum identical to n_frames separate Render calls.
 // The frame's RT_UNIT-pixel units are dealt round-robin over the waves (no shared counter: one atomic word serves only ~88
 // requests per microsecond, too few for a 0.2 ms frame), so every wave gets the same number of units to within one.
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, bool ORDERED>
 __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
 {
     const uint32_t lane = threadIdx.x & 63u;
@@ -716,7 +734,7 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
         // ---- one bounce for every lane with a path
         if (live) {
             int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
-            if (path_step<MODE, STATS>(s, p, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris)) {
+            if (path_step<MODE, STATS, ORDERED>(s, p, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris)) {
                 if (id_out && p.bounces == 0) *id_out = -1;
                 acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
                 frame++;
@@ -781,40 +799,40 @@ __global__ __launch_bounds__(256) void rt_aa_kernel(RtParams p, uint32_t frame_i
 }
 
 // ---- launchers (called from rt_api.cpp) -----------------------------------------------------------------------------
-template <int MODE, bool STATS>
-static hipError_t occupancy_of(int* blocks_per_cu)
+// Dispatch over (mode, stats, ordered); sphere-only frames have no tree to order.
+template <class F>
+static hipError_t for_variant(int mode, int stats, int ordered, F&& f)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, rt_trace_kernel<MODE, STATS>, 256, 0);
-}
-
-// Resident workgroups per CU of the trace kernel for (mode, stats): sizes the persistent grid.
-extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int* blocks_per_cu)
-{
-    switch (mode * 2 + (stats ? 1 : 0)) {
-    case 0: return occupancy_of<RT_MODE_MESH, false>(blocks_per_cu);
-    case 1: return occupancy_of<RT_MODE_MESH, true>(blocks_per_cu);
-    case 2: return occupancy_of<RT_MODE_SPHERES, false>(blocks_per_cu);
-    case 3: return occupancy_of<RT_MODE_SPHERES, true>(blocks_per_cu);
-    case 4: return occupancy_of<RT_MODE_BOTH, false>(blocks_per_cu);
-    default: return occupancy_of<RT_MODE_BOTH, true>(blocks_per_cu);
+    const int key = (mode * 2 + (stats ? 1 : 0)) * 2 + ((ordered && mode != RT_MODE_SPHERES) ? 1 : 0);
+    switch (key) {
+    case 0:  return f(rt_trace_kernel<RT_MODE_MESH, false, false>);
+    case 1:  return f(rt_trace_kernel<RT_MODE_MESH, false, true>);
+    case 2:  return f(rt_trace_kernel<RT_MODE_MESH, true, false>);
+    case 3:  return f(rt_trace_kernel<RT_MODE_MESH, true, true>);
+    case 4:  return f(rt_trace_kernel<RT_MODE_SPHERES, false, false>);
+    case 6:  return f(rt_trace_kernel<RT_MODE_SPHERES, true, false>);
+    case 8:  return f(rt_trace_kernel<RT_MODE_BOTH, false, false>);
+    case 9:  return f(rt_trace_kernel<RT_MODE_BOTH, false, true>);
+    case 10: return f(rt_trace_kernel<RT_MODE_BOTH, true, false>);
+    case 11: return f(rt_trace_kernel<RT_MODE_BOTH, true, true>);
+    default: return hipErrorInvalidValue;
     }
 }
 
-template <int MODE>
-static void launch_mode(const RtParams& p, unsigned grid, bool stats, hipStream_t s)
+// Resident workgroups per CU of the trace kernel variant: sizes the persistent grid.
+extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* blocks_per_cu)
 {
-    if (stats) hipLaunchKernelGGL((rt_trace_kernel<MODE, true>), dim3(grid), dim3(256), 0, s, p);
-    else       hipLaunchKernelGGL((rt_trace_kernel<MODE, false>), dim3(grid), dim3(256), 0, s, p);
+    return for_variant(mode, stats, ordered, [&](auto kernel) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, 256, 0);
+    });
 }
 
-extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, unsigned grid, hipStream_t s)
+extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, int ordered, unsigned grid, hipStream_t s)
 {
-    switch (mode) {
-    case RT_MODE_MESH:    launch_mode<RT_MODE_MESH>(*p, grid, stats != 0, s); break;
-    case RT_MODE_SPHERES: launch_mode<RT_MODE_SPHERES>(*p, grid, stats != 0, s); break;
-    default:              launch_mode<RT_MODE_BOTH>(*p, grid, stats != 0, s); break;
-    }
-    return hipGetLastError();
+    return for_variant(mode, stats, ordered, [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, *p);
+        return hipGetLastError();
+    });
 }
 
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s)

@@ -18,7 +18,8 @@ from .scenes import MATERIAL_DTYPE, SPHERE_DTYPE
 
 class Settings:
     """Renderer::Settings (Renderer.h:103-110).  `SceneMode` (None = follow UseSphereScene) selects the added
-    spheres+mesh mode; `Seed` seeds the per-(pixel, frame) random streams."""
+    spheres+mesh mode; `Seed` seeds the per-(pixel, frame) random streams; `TraversalOrder` is the KD tree walk
+    order (_capi.ORDER_AUTO / ORDER_REFERENCE / ORDER_FRONT_TO_BACK, see include/rt_mi355x.h)."""
 
     def __init__(self):
         self.Render = True
@@ -29,6 +30,7 @@ class Settings:
         self.Bounces = 8
         self.SceneMode = None
         self.Seed = 1337
+        self.TraversalOrder = _capi.ORDER_AUTO
 
     def scene_mode(self):
         if self.SceneMode is not None:
@@ -37,7 +39,7 @@ class Settings:
 
     def to_c(self):
         return RtSettings(int(bool(self.Accumulate)), self.scene_mode(), int(bool(self.UseACE_Color)),
-                          int(bool(self.AntiAliasing)), int(self.Bounces), int(self.Seed))
+                          int(bool(self.AntiAliasing)), int(self.Bounces), int(self.Seed), int(self.TraversalOrder))
 
 
 class KDTree:
@@ -253,6 +255,16 @@ class Renderer:
 
     def record_ids(self, on=True):
         check(self._h, self._L.rt_set_record_ids(self._h, int(on)), "rt_set_record_ids")
+
+    def push_settings(self):
+        """Send GetSettings() to the library without the rest of upload()."""
+        st = self.m_settings.to_c()
+        check(self._h, self._L.rt_set_settings(self._h, C.byref(st)), "rt_set_settings")
+
+    def traversal_in_use(self):
+        """_capi.ORDER_REFERENCE or ORDER_FRONT_TO_BACK: what the current settings and tree resolve to (after upload)."""
+        self.push_settings()
+        return self._L.rt_traversal_in_use(self._h)
 
     def set_stats(self, on=True):
         check(self._h, self._L.rt_set_stats(self._h, int(on)), "rt_set_stats")

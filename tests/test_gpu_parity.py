@@ -2,7 +2,9 @@
 scenes, camera, settings and per-(pixel, frame) random streams.
 
 Bar: primary-hit ids bit-exact, accumulated radiance bit-exact (so also within the stated tolerance
-|d| <= 1e-5 + 1e-5*|ref|), the tone-mapped RGBA32F frame bit-exact, ray/node/triangle counters equal.
+|d| <= 1e-5 + 1e-5*|ref|), the tone-mapped RGBA32F frame bit-exact, ray counters equal.  Mesh scenes run in both tree
+walk orders: in the reference order the node/triangle counters must equal the oracle's as well (same visited set ray by
+ray); front to back must give the same ids, radiance and image with no more nodes and triangles.
 """
 import os
 
@@ -49,13 +51,18 @@ def make_scene(rt, orc, mesh=None, spheres=True, mats_extra=None):
     return scene, osc
 
 
+REF_ORDER, F2B_ORDER = 1, 2          # _capi.ORDER_REFERENCE, _capi.ORDER_FRONT_TO_BACK
+ORDERS = [pytest.param(REF_ORDER, id="reference-order"), pytest.param(F2B_ORDER, id="front-to-back")]
+
+
 def run_both(rt, orc, r, scene, osc, w, h, mode, bounces, frames, use_ace=True, aa=False, seed=1337, stats=False,
-             cam=None, threads=8):
+             cam=None, threads=8, order=0):
     if cam is None:
         cam = rt.Camera(70.0, 0.05, 100.0)
     cam.OnResize(w, h)
     st = r.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, bounces, use_ace, aa, True, seed
+    st.TraversalOrder = order
     r.OnResize(w, h)
     r.ResetFrameIndex()
     r.record_ids(True)
@@ -73,6 +80,7 @@ def run_both(rt, orc, r, scene, osc, w, h, mode, bounces, frames, use_ace=True, 
                cnt=r.read_counters())
     want = dict(ids=ids, acc=acc, img=img, cnt=cnt)
     r.set_stats(False)
+    st.TraversalOrder = 0
     return got, want
 
 
@@ -85,6 +93,16 @@ def assert_exact(got, want, counters=("rays",)):
     assert np.array_equal(bits(got["img"]), bits(want["img"])), "image differs"
     for k in counters:
         assert getattr(got["cnt"], k) == getattr(want["cnt"], k), (k, getattr(got["cnt"], k), getattr(want["cnt"], k))
+
+
+def assert_mesh(got, want, order, extra=()):
+    """Reference order: the same nodes and triangles as the oracle.  Front to back: same result, no more work."""
+    if order == REF_ORDER:
+        assert_exact(got, want, ("rays", "nodes_visited", "tris_tested") + tuple(extra))
+    else:
+        assert_exact(got, want, ("rays",) + tuple(extra))
+        assert 0 < got["cnt"].nodes_visited <= want["cnt"].nodes_visited
+        assert got["cnt"].tris_tested <= want["cnt"].tris_tested
 
 
 # ---- spheres --------------------------------------------------------------------------------------------------------------
@@ -167,14 +185,56 @@ def test_host_supplied_ray_directions(rt, orc, renderer):
 
 
 # ---- mesh through the KD tree ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("name", ["grid40", "cubesphere16"])
-def test_mesh_bit_exact_with_counters(rt, orc, renderer, name):
+def test_mesh_bit_exact_with_counters(rt, orc, renderer, name, order):
     from raytracer_amd import scenes
     mesh = scenes.displaced_grid(40) if name == "grid40" else scenes.cube_sphere(16)
     scene, osc = make_scene(rt, orc, mesh=mesh)
-    got, want = run_both(rt, orc, renderer, scene, osc, 160, 90, 0, 8, 3, stats=True)
-    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested"))
+    got, want = run_both(rt, orc, renderer, scene, osc, 160, 90, 0, 8, 3, stats=True, order=order)
+    assert_mesh(got, want, order)
     assert (want["ids"] >= 0).sum() > 500 and (want["ids"] < 0).sum() > 500
+    if order == F2B_ORDER:                          # strictly less work (the rays of the direction.x == 0 column, which
+        assert got["cnt"].tris_tested < want["cnt"].tris_tested      # nothing can prune, dominate both counts at this size)
+
+
+@pytest.mark.parametrize("side", [(1.0, 0.3, 0.2), (-0.5, -0.8, 0.6), (0.2, 0.4, -1.0), (-0.7, 0.9, -0.4)])
+def test_mesh_orders_agree_from_other_viewpoints(rt, orc, renderer, side):
+    """Cameras on different sides of the mesh, looking at it, so that the rays fall into other sign patterns (each pattern
+    walks its own node array): both orders against the oracle."""
+    from raytracer_amd import scenes
+    centre = np.array([0.0, 0.6, -0.8], np.float32)
+    scene, osc = make_scene(rt, orc, mesh=scenes.cube_sphere(14, center=tuple(centre), radius=0.7))
+    d = np.array(side, np.float32); d /= np.linalg.norm(d)
+    cam = rt.Camera(70.0, 0.05, 100.0)
+    cam.SetPose((centre + np.float32(1.9) * d).astype(np.float32), (-d).astype(np.float32))
+    for order in (REF_ORDER, F2B_ORDER):
+        got, want = run_both(rt, orc, renderer, scene, osc, 144, 96, 0, 6, 2, stats=True, cam=cam, order=order)
+        assert_mesh(got, want, order)
+    assert (want["ids"] >= 0).sum() > 1000
+
+
+def test_auto_order_follows_the_tree(rt, orc, renderer):
+    """A tree of the reference builder is a KD tree: RT_ORDER_AUTO walks it front to back.  The same tree with two sibling
+    boxes swapped in position is not (its children no longer tile their parent): AUTO falls back to the reference order."""
+    from raytracer_amd import scenes, _capi
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(24))
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(64, 48)
+    st = renderer.GetSettings(); st.SceneMode, st.TraversalOrder = 0, _capi.ORDER_AUTO
+    renderer.OnResize(64, 48); renderer.upload(scene, cam)
+    assert renderer.traversal_in_use() == _capi.ORDER_FRONT_TO_BACK
+    a = scene.kd_tree.arrays()
+    ext = a["extent"].copy()
+    two = np.flatnonzero((a["left"] >= 0) & (a["right"] >= 0))[0]
+    ext[a["left"][two]] *= np.float32(0.5)                               # the left child no longer reaches the split plane
+    scene2 = rt.Scene(); scene2.materials = scene.materials; scene2.spheres = scene.spheres
+    scene2.set_triangles(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat, build_kd=False)
+    scene2.kd_tree = rt.FlatKDTree(a["center"], ext, a["left"], a["right"], a["first"], a["count"], a["leaf_idx"])
+    renderer.upload(scene2, cam)
+    assert renderer.traversal_in_use() == _capi.ORDER_REFERENCE
+    st.TraversalOrder = _capi.ORDER_FRONT_TO_BACK
+    assert renderer.traversal_in_use() == _capi.ORDER_FRONT_TO_BACK
+    st.TraversalOrder = _capi.ORDER_AUTO
 
 
 def test_mesh_centred_on_zero_direction_column(rt, orc, renderer):
@@ -182,8 +242,9 @@ def test_mesh_centred_on_zero_direction_column(rt, orc, renderer):
     * inf = NaN in the slab test: the reference counts such boxes as hit and never prunes them."""
     from raytracer_amd import scenes
     scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(32))
-    got, want = run_both(rt, orc, renderer, scene, osc, 64, 48, 0, 4, 2, stats=True)
-    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested"))
+    for order in (REF_ORDER, F2B_ORDER):
+        got, want = run_both(rt, orc, renderer, scene, osc, 64, 48, 0, 4, 2, stats=True, order=order)
+        assert_mesh(got, want, order)
     col = want["ids"].reshape(48, 64)[:, 32]
     assert (col >= 0).any()
 
@@ -206,11 +267,12 @@ def test_reference_built_tree_and_reference_hits(rt, orc, renderer):
     assert np.array_equal(renderer.read_primary_ids().ravel(), g["primary_ids"])
 
 
-def test_spheres_and_mesh_together(rt, orc, renderer):
+@pytest.mark.parametrize("order", ORDERS)
+def test_spheres_and_mesh_together(rt, orc, renderer, order):
     from raytracer_amd import scenes
     scene, osc = make_scene(rt, orc, mesh=scenes.cube_sphere(12, center=(0.2, 0.7, -0.6), radius=0.5))
-    got, want = run_both(rt, orc, renderer, scene, osc, 192, 108, 2, 6, 3, stats=True)
-    assert_exact(got, want, ("rays", "nodes_visited", "tris_tested", "sphere_tests"))
+    got, want = run_both(rt, orc, renderer, scene, osc, 192, 108, 2, 6, 3, stats=True, order=order)
+    assert_mesh(got, want, order, extra=("sphere_tests",))
     tri = (want["ids"] >= 0x40000000).sum(); sph = ((want["ids"] >= 0) & (want["ids"] < 0x40000000)).sum()
     assert tri > 300 and sph > 300
 
@@ -365,17 +427,24 @@ def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
     w, h = 1920, 1080
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
     st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.AntiAliasing, st.Accumulate, st.UseACE_Color, st.Seed = 0, 8, False, True, True, 1337
-    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
-    renderer.Render(scene, cam)
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
     ids, *_ = osc.trace_primary(0, cam.GetPosition(), dirs)
-    got_ids = renderer.read_primary_ids().ravel()
-    assert np.array_equal(got_ids, ids)
     assert (ids >= 0).sum() > 100000
     acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
     osc.render_frame(orc.Settings(1, 0, 1, 0, 8), cam.GetPosition(), dirs, w, h, 1, acc, img, nthreads=16, row_step=16)
     rows = np.arange(0, h, 16)
-    assert np.array_equal(bits(renderer.read_accum()[rows]), bits(acc.reshape(h, w, 3)[rows]))
+    full = {}
+    try:
+        for order in (REF_ORDER, F2B_ORDER):
+            st.TraversalOrder = order
+            renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
+            renderer.Render(scene, cam)
+            assert np.array_equal(renderer.read_primary_ids().ravel(), ids)
+            full[order] = renderer.read_accum()
+            assert np.array_equal(bits(full[order][rows]), bits(acc.reshape(h, w, 3)[rows]))
+    finally:
+        st.TraversalOrder = 0
+    assert np.array_equal(bits(full[REF_ORDER]), bits(full[F2B_ORDER]))      # every pixel, not only the oracle's rows
 
 
 # ---- plumbing for the multi-GPU path, on one GPU ------------------------------------------------------------------------------
@@ -460,8 +529,9 @@ def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
 
 
 # ---- rays with exactly-zero direction components (NaN slab tests) -----------------------------------------------------------
+@pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("mode", [0, 2])
-def test_zero_direction_components_all_patterns(rt, orc, renderer, mode):
+def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
     """Host-supplied directions with +0 / -0 planted in x, y, z (alone and combined) on scattered pixels, next to the default
     camera's own +0 column: the pre-pass (x == +0 primaries), the wave-cooperative walk (x == -0, and any bounce) and the
     ordinary walk (zeros in y / z only) must all reproduce the reference's visited sets and hits."""
@@ -486,6 +556,7 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode):
         else: dirs[px, 0] = pz; dirs[px] *= np.float32(3.0)                        # not unit length
     st = renderer.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, 5, True, False, True, 1337
+    st.TraversalOrder = order
     renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(True); renderer.reset_counters()
     renderer.upload(scene, cam)
     renderer.set_ray_dirs(dirs)
@@ -499,6 +570,6 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode):
         got = dict(ids=renderer.read_primary_ids().ravel(), acc=renderer.read_accum().reshape(-1, 3),
                    img=renderer.GetImage().data.reshape(-1, 4), cnt=renderer.read_counters())
         # NaN never equals NaN bitwise-safe compare is what bits() does; a ray going nowhere yields NaN radiance in both
-        assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=cnt), ("rays", "nodes_visited", "tris_tested"))
+        assert_mesh(got, dict(ids=ids, acc=acc, img=img, cnt=cnt), order)
     finally:
-        renderer.set_ray_dirs(None); renderer.set_stats(False)
+        renderer.set_ray_dirs(None); renderer.set_stats(False); st.TraversalOrder = 0
