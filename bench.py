@@ -39,10 +39,12 @@ CONFIGS = {
     2: dict(name="default sphere scene 1920x1080, 5 bounces, 64 spp (BASELINE configs[1])", w=1920, h=1080, bounces=5, mode=1, mesh=None),
     3: dict(name="69,938-triangle displaced grid + KD tree, 1920x1080, 8 bounces (BASELINE configs[2])", w=1920, h=1080,
             bounces=8, mode=0, mesh=("grid", 187)),
-    4: dict(name="9,999,392-triangle displaced grid + KD tree in HBM, 3840x2160, 8 bounces, screen-tile split (BASELINE configs[3])",
-            w=3840, h=2160, bounces=8, mode=0, mesh=("grid", 2236), split="tile"),
+    # 2236 x 2236 quads over 30 x 30 units: quads of 13 mm.  (Over the 3 x 3 units of config 3 every triangle would fall under
+    # the reference's |determinant| < 1e-5 rejection, Intersections.cpp:64, and the mesh could not be hit at all.)
+    4: dict(name="9,999,392-triangle displaced grid (30x30 units) + KD tree in HBM, 3840x2160, 8 bounces, screen-tile split (BASELINE configs[3])",
+            w=3840, h=2160, bounces=8, mode=0, mesh=("grid", 2236, 10.0), split="tile"),
     5: dict(name="default spheres + 9,999,392-triangle mesh, 3840x2160, 8 bounces, progressive, sample split (BASELINE configs[4])",
-            w=3840, h=2160, bounces=8, mode=2, mesh=("grid", 2236)),
+            w=3840, h=2160, bounces=8, mode=2, mesh=("grid", 2236, 10.0)),
 }
 
 
@@ -53,9 +55,13 @@ def build_scene(cfg):
     scene.spheres = scenes.default_spheres()
     mats = scenes.default_materials()
     if cfg["mesh"]:
-        kind, n = cfg["mesh"]
-        gen = scenes.displaced_grid if kind == "grid" else scenes.cube_sphere
-        verts, tris, normals9, tri_mat, mesh_mats = gen(n, mat_offset=len(mats))
+        kind, n = cfg["mesh"][:2]
+        if kind == "grid":
+            k = cfg["mesh"][2] if len(cfg["mesh"]) > 2 else 1.0
+            verts, tris, normals9, tri_mat, mesh_mats = scenes.displaced_grid(n, x_range=(-1.5 * k, 1.5 * k), z_range=(-3.0 * k, 0.0),
+                                                                              mat_offset=len(mats))
+        else:
+            verts, tris, normals9, tri_mat, mesh_mats = scenes.cube_sphere(n, mat_offset=len(mats))
         scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=min(16, os.cpu_count() or 1))
         mats = np.concatenate([mats, mesh_mats])
     scene.materials = mats

@@ -5,6 +5,7 @@
 // flat host tree and is re-laid out here for the device (preorder + skip links, leaf-ordered pre-gathered triangles).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -76,7 +77,10 @@ struct rt_ctx {
 
     // column rays (primary rays with direction.x == +0): slots found whenever directions or bands change
     static const uint32_t kColumnCap = 1u << 16;
-    DevBuf<uint32_t> d_column_count, d_column_pixels, d_column_flags;
+    static const uint32_t kColumnQueueCap = 1u << 20;
+    DevBuf<uint32_t> d_column_count, d_column_pixels, d_column_flags, d_column_block, d_column_queue_count;
+    DevBuf<float4> d_column_dirs, d_column_boxes;      // boxes: 16-slot, 64-slot, 256-slot arrays back to back
+    DevBuf<uint2> d_column_queue;
     DevBuf<unsigned long long> d_column_best;
     DevBuf<unsigned char> d_reached;
     bool columns_dirty = true;
@@ -145,6 +149,12 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
     p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
     p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr;
+    p.column_dirs = c->d_column_dirs.ptr; p.column_block = c->d_column_block.ptr;
+    p.column_box16 = c->d_column_boxes.ptr;
+    p.column_box64 = p.column_box16 + (rt_ctx::kColumnCap + 15u) / 16u;
+    p.column_box256 = p.column_box64 + (rt_ctx::kColumnCap + 63u) / 64u;
+    p.column_queue = c->d_column_queue.ptr; p.column_queue_count = c->d_column_queue_count.ptr;
+    p.column_queue_cap = rt_ctx::kColumnQueueCap;
 }
 
 // Every material index a kernel can read must be in range: the kernels do not check.
@@ -207,6 +217,9 @@ rt_ctx* rt_create(int device_id)
         hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess ||
         c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
         c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
+        c->d_column_dirs.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_queue_count.resize(1) != hipSuccess ||
+        c->d_column_boxes.resize((rt_ctx::kColumnCap + 15u) / 16u + (rt_ctx::kColumnCap + 63u) / 64u + (rt_ctx::kColumnCap + 255u) / 256u) != hipSuccess ||
+        c->d_column_queue.resize(rt_ctx::kColumnQueueCap) != hipSuccess || hipMemset(c->d_column_queue_count.ptr, 0, 4) != hipSuccess ||
         hipMemset(c->d_column_count.ptr, 0, 4) != hipSuccess || hipMemset(c->d_column_flags.ptr, 0, 4) != hipSuccess) {
         fail(nullptr, RT_E_HIP, "device query / counter allocation failed on device %d", device_id);
         rt_destroy(c); return nullptr;
@@ -224,6 +237,7 @@ void rt_destroy(rt_ctx* c)
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release();
     c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
+    c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
@@ -531,10 +545,17 @@ int ensure_dirs(rt_ctx* c, const RtParams& p)
 }
 
 // Column rays of the current directions/bands: slots into dirs[].w, count read back once (only when something changed).
-int ensure_columns(rt_ctx* c, const RtParams& p)
+int ensure_columns(rt_ctx* c, RtParams& p)
 {
+    // scratch for the per-block scans: one word per 256 pixels / 256 nodes / 256 slots, whichever is most
+    const size_t blocks = std::max(std::max(((size_t)c->width * c->height + 255) / 256, ((size_t)c->n_nodes + 255) / 256),
+                                   (size_t)(rt_ctx::kColumnCap + 255u) / 256u);
+    if (c->d_column_block.count < blocks) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->d_column_block.resize(blocks));
+        p.column_block = c->d_column_block.ptr;
+    }
     if (!c->columns_dirty) return RT_OK;
-    HIP_TRY(c, hipMemsetAsync(c->d_column_count.ptr, 0, sizeof(uint32_t), c->stream));
     HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

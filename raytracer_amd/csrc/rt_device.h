@@ -61,13 +61,21 @@ struct RtParams {
     float4* image;
     int32_t* primary_ids;                   // optional
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
-    // primary rays with direction.x == +0 ("column rays"): found when directions change, resolved per frame by a pre-pass
+    // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records
     uint32_t  column_cap;
-    uint32_t* column_count;                  // number of column rays (<= column_cap)
-    uint32_t* column_pixels;                 // their pixel indices; dirs[pixel].w holds slot + 1 (0 = not a column ray)
+    uint32_t* column_count;                  // number of column rays (may exceed column_cap: the excess is not numbered)
+    uint32_t* column_pixels;                 // their pixel indices in pixel order; dirs[pixel].w holds slot + 1 (0 = not a column ray)
+    float4*   column_dirs;                   // their directions, by slot
+    float4*   column_box16;                  // { min dy, max dy, min dz, max dz } of the directions of slots 16i .. 16i+15
+    float4*   column_box64;                  // the same for 64 and 256 consecutive slots
+    float4*   column_box256;
+    uint32_t* column_block;                  // scratch: per-block counts / maxima and their scans
+    uint2*    column_queue;                  // (leaf record, 16-slot box) pairs that need the real triangle test
+    uint32_t* column_queue_count;
+    uint32_t  column_queue_cap;
     unsigned long long* column_best;         // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
-    uint32_t* column_flags;                  // bit 0: the pre-pass may not be used (some decision depended on t)
+    uint32_t* column_flags;                  // bit 0: the pre-pass result may not be used (a decision depended on t, or the queue overflowed)
     unsigned char* reached;                  // per node: visited by column rays (pre-pass scratch)
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

@@ -538,98 +538,270 @@ __global__ __launch_bounds__(256) void rt_raygen_kernel(RtParams p)
 }
 
 // ---- column rays: primary rays with direction.x == +0 (see trace_mesh_cooperative for why they cannot be pruned) ------------
-// They share the origin and, because the NaN of the x slab overrides the other two axes, the same set of visited leaves.
-// rt_column_collect finds them when the directions change; per frame rt_column_reach marks the visited nodes once and
-// rt_column_test tries every record of a visited leaf against every column ray, keeping min (t, record index) per ray.
-__global__ __launch_bounds__(256) void rt_column_collect_kernel(RtParams p)
+// They share the origin and, because the NaN of the x slab overrides the other two axes, the same set of visited leaves: about
+// half the tree, whatever the ray looks at.  Tracing them lane by lane costs ~10^5 dependent steps per ray, so they are resolved
+// for the whole frame by a pre-pass instead:
+//   when the directions change : rt_column_count / _scan / _assign number them in pixel order (slot + 1 goes into dirs[].w, the
+//                                directions into a compact array) and rt_column_chunks boxes the directions of every 16, 64 and
+//                                256 consecutive slots;
+//   every frame                : rt_column_reach_* marks the visited nodes (a prefix maximum over the preorder array),
+//                                rt_column_filter proves, per visited leaf record and per box of rays, that no ray of the box can
+//                                pass the triangle test, and queues the (record, 16 rays) pairs it cannot decide;
+//                                rt_column_exact runs the real triangle test on those and keeps min (t, record index) per ray.
+// The proof is interval arithmetic over the very operations of tri_test: every floating-point operation is monotone in each
+// operand and rounding is monotone, so the values tri_test would compute for ANY ray of the box lie between the values
+// computed at the corners of the box.  A pair is dropped only when a rejecting comparison of tri_test holds over the whole
+// interval, i.e. for every ray in it; everything else is tested exactly.  Result: bit for bit what testing every record
+// against every column ray gives, at a few percent of the work.
+
+struct Iv { float lo, hi; };
+__device__ __forceinline__ Iv iv_mul_scalar(Iv a, float b)          // a * b, b one value
 {
-    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
-    if (pixel >= p.width * p.height) return;
-    const uint32_t y = pixel / p.width;
-    float4 d = p.dirs_out[pixel];
-    uint32_t slot1 = 0;
-    const bool owned = ((y / RT_TILE) % p.band_count) == p.band_index;
-    if (owned && __float_as_uint(d.x) == 0u) {                  // +0 exactly; -0 rays take the in-kernel path
-        const uint32_t slot = atomicAdd(p.column_count, 1u);
-        if (slot < p.column_cap) { p.column_pixels[slot] = pixel; slot1 = slot + 1u; }
-    }
-    d.w = __uint_as_float(slot1);
-    p.dirs_out[pixel] = d;
+    const float x = a.lo * b, y = a.hi * b;
+    Iv r; r.lo = (y < x) ? y : x; r.hi = (y < x) ? x : y; return r;
+}
+__device__ __forceinline__ Iv iv_mul(Iv a, Iv b)
+{
+    const float p0 = a.lo * b.lo, p1 = a.lo * b.hi, p2 = a.hi * b.lo, p3 = a.hi * b.hi;
+    const float l01 = (p1 < p0) ? p1 : p0, h01 = (p1 < p0) ? p0 : p1;
+    const float l23 = (p3 < p2) ? p3 : p2, h23 = (p3 < p2) ? p2 : p3;
+    Iv r; r.lo = (l23 < l01) ? l23 : l01; r.hi = (h01 < h23) ? h23 : h01; return r;
+}
+__device__ __forceinline__ Iv iv_add(Iv a, Iv b) { Iv r; r.lo = a.lo + b.lo; r.hi = a.hi + b.hi; return r; }
+__device__ __forceinline__ Iv iv_sub(Iv a, Iv b) { Iv r; r.lo = a.lo - b.hi; r.hi = a.hi - b.lo; return r; }
+
+// What a leaf record contributes to tri_test independently of the ray (all column rays start at the camera position).
+struct ColumnTri { F3 e1, e2, s; float qy, qz, e2q; };
+
+__device__ __forceinline__ ColumnTri column_tri(float4 r0, float4 r1, float4 r2, F3 O)
+{
+    ColumnTri c;
+    const F3 v0 = f3(r0.x, r0.y, r0.z);
+    c.e1 = f3(r0.w, r1.x, r1.y); c.e2 = f3(r1.z, r1.w, r2.x);
+    c.s = O - v0;
+    const F3 q = cross3(c.s, c.e1);
+    c.qy = q.y; c.qz = q.z;
+    c.e2q = dot3(c.e2, q);
+    return c;
 }
 
-// One workgroup walks the preorder node array in 1024-node windows for the ray of column slot 0 (any column ray gives the
-// same decisions): reached[node] = 1 for visited nodes whose box counts as hit.  Also clears the per-ray results.
-__global__ __launch_bounds__(1024) void rt_column_reach_kernel(RtParams p, int stats)
+// True when tri_test fails for EVERY direction (+0, dy, dz) with dy in [b.x, b.y], dz in [b.z, b.w].  With direction.x == +0
+// tri_test's h = cross(D, e2) is (dy*e2.z - e2.y*dz, dz*e2.x, -(e2.x*dy)) and dot(D, q) is dy*q.y + dz*q.z: the terms
+// multiplied by the zero vanish exactly (x - 0 = x, 0 - x = -x, 0 + x = x for finite values).
+__device__ __forceinline__ bool column_box_rejects(const ColumnTri& c, float4 b)
 {
-    __shared__ uint32_t wave_max[16];
-    __shared__ uint32_t s_killed_to, s_dependent, s_nodes;
+    const Iv DY = {b.x, b.y}, DZ = {b.z, b.w};
+    const Iv hx = iv_sub(iv_mul_scalar(DY, c.e2.z), iv_mul_scalar(DZ, c.e2.y));
+    const Iv hy = iv_mul_scalar(DZ, c.e2.x);
+    const Iv t0 = iv_mul_scalar(DY, c.e2.x);
+    const Iv hz = {-t0.hi, -t0.lo};
+    const Iv a = iv_add(iv_add(iv_mul_scalar(hx, c.e1.x), iv_mul_scalar(hy, c.e1.y)), iv_mul_scalar(hz, c.e1.z));
+    if (a.lo > -0.00001f && a.hi < 0.00001f) return true;           // "a > -EPS && a < EPS" for every ray
+    if (!(a.lo > 1e-30f || a.hi < -1e-30f)) return false;           // some ray may see a (near) zero determinant
+    const Iv f = {1.0f / a.hi, 1.0f / a.lo};
+    const Iv du = iv_add(iv_add(iv_mul_scalar(hx, c.s.x), iv_mul_scalar(hy, c.s.y)), iv_mul_scalar(hz, c.s.z));
+    const Iv u = iv_mul(f, du);
+    if (u.hi < 0.0f || u.lo > 1.0f) return true;
+    const Iv dv = iv_add(iv_mul_scalar(DY, c.qy), iv_mul_scalar(DZ, c.qz));
+    const Iv v = iv_mul(f, dv);
+    if (v.hi < 0.0f || u.lo + v.lo > 1.0f) return true;
+    const Iv t = iv_mul_scalar(f, c.e2q);
+    return !(t.hi > 0.00001f);
+}
+
+// -- numbering (runs when directions, bands or size change) --
+__device__ __forceinline__ bool is_column_pixel(const RtParams& p, uint32_t pixel, float4& d)
+{
+    if (pixel >= p.width * p.height) return false;
+    const uint32_t y = pixel / p.width;
+    d = p.dirs_out[pixel];
+    const bool owned = ((y / RT_TILE) % p.band_count) == p.band_index;
+    return owned && __float_as_uint(d.x) == 0u;                     // +0 exactly; -0 rays take the in-kernel path
+}
+
+__global__ __launch_bounds__(256) void rt_column_count_kernel(RtParams p)
+{
+    __shared__ uint32_t wave_count[4];
+    float4 d;
+    const bool is = is_column_pixel(p, blockIdx.x * 256u + threadIdx.x, d);
+    const uint32_t n = (uint32_t)__popcll(__ballot(is));
+    if ((threadIdx.x & 63u) == 0u) wave_count[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) p.column_block[blockIdx.x] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+}
+
+// Exclusive prefix sum of the per-block counts, in place, by one workgroup; the total goes to *column_count.
+__global__ __launch_bounds__(1024) void rt_column_scan_kernel(RtParams p, uint32_t n_blocks)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += p.column_block[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {               // Hillis-Steele inclusive scan
+        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = p.column_block[i]; p.column_block[i] = run; run += c; }
+    if (tid == 1023u) *p.column_count = part[1023];
+}
+
+__global__ __launch_bounds__(256) void rt_column_assign_kernel(RtParams p)
+{
+    __shared__ uint32_t wave_count[4];
+    const uint32_t pixel = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    float4 d;
+    const bool is = is_column_pixel(p, pixel, d);
+    const unsigned long long m = __ballot(is);
+    if (lane == 0u) wave_count[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t slot = p.column_block[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    for (uint32_t w = 0; w < wv; ++w) slot += wave_count[w];
+    if (pixel < p.width * p.height) {
+        uint32_t slot1 = 0u;
+        if (is && slot < p.column_cap) {
+            p.column_pixels[slot] = pixel;
+            p.column_dirs[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+            slot1 = slot + 1u;
+        }
+        d.w = __uint_as_float(slot1);
+        p.dirs_out[pixel] = d;
+    }
+}
+
+// Boxes of the directions of 16, 64 and 256 consecutive slots: { min dy, max dy, min dz, max dz }.  A box holding a
+// non-finite or huge component must not be used for the proof: it is stored with dy_lo = NaN, which the filter checks first.
+__global__ __launch_bounds__(256) void rt_column_chunks_kernel(RtParams p)
+{
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t first, last; float4* out;
+    if (i < n16) { first = i * 16u; last = first + 16u; out = p.column_box16 + i; }
+    else if (i < n16 + n64) { first = (i - n16) * 64u; last = first + 64u; out = p.column_box64 + (i - n16); }
+    else if (i < n16 + n64 + n256) { first = (i - n16 - n64) * 256u; last = first + 256u; out = p.column_box256 + (i - n16 - n64); }
+    else return;
+    if (last > count) last = count;
+    float ylo = __builtin_inff(), yhi = -__builtin_inff(), zlo = ylo, zhi = yhi;
+    bool usable = true;
+    for (uint32_t k = first; k < last; ++k) {
+        const float4 d = p.column_dirs[k];
+        usable = usable && (fabsf(d.y) < 1e9f) && (fabsf(d.z) < 1e9f);      // false for NaN and infinities too
+        ylo = (d.y < ylo) ? d.y : ylo; yhi = (d.y > yhi) ? d.y : yhi;
+        zlo = (d.z < zlo) ? d.z : zlo; zhi = (d.z > zhi) ? d.z : zhi;
+    }
+    *out = usable ? make_float4(ylo, yhi, zlo, zhi) : make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+}
+
+// -- per frame --
+// Visited nodes.  In the preorder array a node is skipped exactly when some earlier node whose box the ray misses has a skip
+// link beyond it (that node is an ancestor, or lies in an already skipped subtree whose range is nested in an ancestor's), so
+// "visited" is an exclusive prefix maximum of (box missed ? skip link : 0) compared with the node's own index.  Three steps:
+// per-block maxima, a scan of those by one workgroup, the per-node result.  The ray of slot 0 stands for all column rays.
+__device__ __forceinline__ uint32_t column_kill_end(const RtParams& p, uint32_t j, F3 O, F3 invD, bool& box, float& tNear)
+{
+    box = false; tNear = 0.0f;
+    if (j >= p.n_nodes) return 0u;
+    const float4 n0 = p.nodes[2 * (size_t)j], n1 = p.nodes[2 * (size_t)j + 1];
+    box = slab_test(n0, n1, O, invD, tNear);
+    return box ? 0u : __float_as_uint(n0.w);
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v, uint32_t lane)
+{
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off);
+        if ((int)lane >= off) v = v > o ? v : o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
+{
+    __shared__ uint32_t wave_max[4];
     const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
     if (count == 0u) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < count; i += 1024u) p.column_best[i] = ~0ull;
-    if (tid == 0) { s_killed_to = 0u; s_dependent = 0u; s_nodes = 0u; }
-    const float4 d4 = p.dirs[p.column_pixels[0]];
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid < count) p.column_best[gid] = ~0ull;                    // fresh results for this frame (grid covers column_cap)
+    if (gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }
+    const float4 d4 = p.column_dirs[0];
     const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
     const F3 invD = f3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
-    const uint32_t end = p.n_nodes;
-    uint32_t base = 0, my_nodes = 0;
-    bool dependent = false;
+    bool box; float tNear;
+    uint32_t m = column_kill_end(p, gid, O, invD, box, tNear);
+    m = wave_inclusive_max(m, threadIdx.x & 63u);
+    if ((threadIdx.x & 63u) == 63u) wave_max[threadIdx.x >> 6] = m;
     __syncthreads();
-    while (base < end) {
-        const uint32_t killed_to = s_killed_to;
-        const uint32_t j = base + tid;
-        const bool valid = j < end;
-        float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
-        if (valid) { n0 = p.nodes[2 * (size_t)j]; n1 = p.nodes[2 * (size_t)j + 1]; }
-        float tNear;
-        const bool box = slab_test(n0, n1, O, invD, tNear);
-        const uint32_t kill_end = (valid && !box) ? __float_as_uint(n0.w) : 0u;
-        uint32_t pm = kill_end;                                 // inclusive prefix maximum inside the wave
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(pm, off);
-            if ((int)lane >= off) pm = pm > o ? pm : o;
-        }
-        if (lane == 63u) wave_max[wv] = pm;
-        __syncthreads();
-        uint32_t before = killed_to;                            // maximum over the earlier waves of the window
-        for (uint32_t w = 0; w < wv; ++w) before = before > wave_max[w] ? before : wave_max[w];
-        uint32_t excl = __shfl_up(pm, 1);
-        if (lane == 0u) excl = 0u;
-        const uint32_t limit = excl > before ? excl : before;
-        const bool visited = valid && j >= limit;
-        if (visited) {
-            my_nodes++;
-            if (box && tNear == tNear) dependent = true;
-        }
-        if (valid) p.reached[j] = (visited && box) ? 1 : 0;
-        if (tid == 0) {
-            uint32_t all = killed_to;
-            for (uint32_t w = 0; w < 16u; ++w) all = all > wave_max[w] ? all : wave_max[w];
-            s_killed_to = all;
-        }
-        __syncthreads();
-        base += 1024u;
-        const uint32_t k = s_killed_to;
-        if (k > base) {                                         // nodes up to k lie in a rejected subtree: mark and jump
-            for (uint32_t i = base + tid; i < k && i < end; i += 1024u) p.reached[i] = 0;
-            base = k;
-        }
-        __syncthreads();
-    }
-    if (dependent) s_dependent = 1u;
-    if (stats) atomicAdd(&s_nodes, my_nodes);
-    __syncthreads();
-    if (tid == 0) {
-        *p.column_flags = s_dependent ? 1u : 0u;
-        if (stats && !s_dependent) p.counters[1] += (unsigned long long)s_nodes * count;   // every column ray visits these nodes
+    if (threadIdx.x == 0) {
+        uint32_t a = wave_max[0] > wave_max[1] ? wave_max[0] : wave_max[1];
+        uint32_t b = wave_max[2] > wave_max[3] ? wave_max[2] : wave_max[3];
+        p.column_block[blockIdx.x] = a > b ? a : b;
     }
 }
 
-// One lane per leaf record: records of visited leaves are tested against every column ray.
-__global__ __launch_bounds__(256) void rt_column_test_kernel(RtParams p, int stats)
+// Exclusive prefix maximum of the per-block maxima, in place, by one workgroup.
+__global__ __launch_bounds__(1024) void rt_column_reach_scan_kernel(RtParams p, uint32_t n_blocks)
+{
+    __shared__ uint32_t part[1024];
+    if ((*p.column_count < p.column_cap ? *p.column_count : p.column_cap) == 0u) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    uint32_t mx = 0;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.column_block[i]; mx = mx > v ? mx : v; }
+    part[tid] = mx;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {
+        const uint32_t v = tid >= off ? part[tid - off] : 0u;
+        __syncthreads();
+        part[tid] = part[tid] > v ? part[tid] : v;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.column_block[i]; p.column_block[i] = run; run = run > v ? run : v; }
+}
+
+__global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, int stats)
+{
+    __shared__ uint32_t wave_max[4];
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    if (count == 0u) return;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const float4 d4 = p.column_dirs[0];
+    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+    const F3 invD = f3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
+    bool box; float tNear;
+    const uint32_t own = column_kill_end(p, j, O, invD, box, tNear);
+    const uint32_t incl = wave_inclusive_max(own, lane);
+    if (lane == 63u) wave_max[wv] = incl;
+    __syncthreads();
+    uint32_t before = p.column_block[blockIdx.x];                   // maximum over all earlier blocks
+    for (uint32_t w = 0; w < wv; ++w) before = before > wave_max[w] ? before : wave_max[w];
+    uint32_t excl = __shfl_up(incl, 1);
+    if (lane == 0u) excl = 0u;
+    const uint32_t limit = excl > before ? excl : before;
+    const bool visited = j < p.n_nodes && j >= limit;
+    if (j < p.n_nodes) p.reached[j] = (visited && box) ? 1 : 0;
+    // a visited box with a real t_near could be pruned by the closest t so far: then the visited set is not fixed
+    if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.column_flags, 1u);
+    if (stats) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(visited));
+        if (lane == 0u && n) atomicAdd(&p.counters[1], (unsigned long long)n * count);     // every column ray visits these nodes
+    }
+}
+
+// One lane per leaf record of a visited leaf: boxes of 256, then 64, then 16 rays; what cannot be proven a miss is queued.
+__global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int stats)
 {
     const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
-    if (count == 0u || (*p.column_flags & 1u)) return;
+    if (count == 0u) return;
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     bool use = false;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
@@ -641,16 +813,54 @@ __global__ __launch_bounds__(256) void rt_column_test_kernel(RtParams p, int sta
     const unsigned long long any = __ballot(use);
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(any);
-        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.counters[2], (unsigned long long)n * count);
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.counters[2], (unsigned long long)n * count);   // the tests the reference makes
     }
-    if (any == 0ull) return;
+    if (!use) return;
     const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    for (uint32_t s = 0; s < count; ++s) {
-        const float4 d4 = p.dirs[p.column_pixels[s]];           // wave-uniform
+    const ColumnTri c = column_tri(r0, r1, r2, O);
+    // the proof needs finite, moderate numbers (no overflow, no 0 * infinity): otherwise every pair is tested exactly
+    const float big = 1e9f;
+    const bool tame = fabsf(c.s.x) < big && fabsf(c.s.y) < big && fabsf(c.s.z) < big && fabsf(c.e1.x) < big && fabsf(c.e1.y) < big &&
+                      fabsf(c.e1.z) < big && fabsf(c.e2.x) < big && fabsf(c.e2.y) < big && fabsf(c.e2.z) < big;
+    const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
+    for (uint32_t c256 = 0; c256 < n256; ++c256) {
+        const float4 b256 = p.column_box256[c256];
+        if (tame && b256.x == b256.x && column_box_rejects(c, b256)) continue;
+        const uint32_t e64 = (c256 * 4u + 4u < n64) ? c256 * 4u + 4u : n64;
+        for (uint32_t c64 = c256 * 4u; c64 < e64; ++c64) {
+            const float4 b64 = p.column_box64[c64];
+            if (tame && b64.x == b64.x && column_box_rejects(c, b64)) continue;
+            const uint32_t e16 = (c64 * 4u + 4u < n16) ? c64 * 4u + 4u : n16;
+            for (uint32_t c16 = c64 * 4u; c16 < e16; ++c16) {
+                const float4 b16 = p.column_box16[c16];
+                if (tame && b16.x == b16.x && column_box_rejects(c, b16)) continue;
+                const uint32_t at = atomicAdd(p.column_queue_count, 1u);
+                if (at < p.column_queue_cap) p.column_queue[at] = make_uint2(r, c16);
+                else atomicOr(p.column_flags, 1u);                  // queue full: the trace kernel walks these rays itself
+            }
+        }
+    }
+}
+
+// The real triangle test for the queued (record, 16 rays) pairs: 16 lanes per pair.
+__global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
+{
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    if (count == 0u || (*p.column_flags & 1u)) return;
+    const uint32_t n = *p.column_queue_count < p.column_queue_cap ? *p.column_queue_count : p.column_queue_cap;
+    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
+    const uint32_t sub = threadIdx.x & 15u;
+    for (uint32_t e = blockIdx.x * 16u + (threadIdx.x >> 4); e < n; e += gridDim.x * 16u) {
+        const uint2 pr = p.column_queue[e];
+        const uint32_t ray = pr.y * 16u + sub;
+        if (ray >= count) continue;
+        const float4* rec = p.leafrecs + 3 * (size_t)pr.x;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const float4 d4 = p.column_dirs[ray];
         float tt, u, v;
-        if (use && tri_test(r0, r1, r2, O, f3(d4.x, d4.y, d4.z), tt, u, v)) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
-            if (key < p.column_best[s]) atomicMin(&p.column_best[s], key);
+        if (tri_test(r0, r1, r2, O, f3(d4.x, d4.y, d4.z), tt, u, v)) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)pr.x;
+            atomicMin(&p.column_best[ray], key);
         }
     }
 }
@@ -842,17 +1052,28 @@ extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s)
     return hipGetLastError();
 }
 
+// Number the column rays of the current directions (pixel order) and box their directions.
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s)
 {
-    const unsigned n = p->width * p->height;
-    hipLaunchKernelGGL(rt_column_collect_kernel, dim3((n + 255u) / 256u), dim3(256), 0, s, *p);
+    const unsigned n = p->width * p->height, blocks = (n + 255u) / 256u;
+    hipLaunchKernelGGL(rt_column_count_kernel, dim3(blocks), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(rt_column_scan_kernel, dim3(1), dim3(1024), 0, s, *p, blocks);
+    hipLaunchKernelGGL(rt_column_assign_kernel, dim3(blocks), dim3(256), 0, s, *p);
+    const unsigned boxes = (p->column_cap + 15u) / 16u + (p->column_cap + 63u) / 64u + (p->column_cap + 255u) / 256u;
+    hipLaunchKernelGGL(rt_column_chunks_kernel, dim3((boxes + 255u) / 256u), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s)
 {
-    hipLaunchKernelGGL(rt_column_reach_kernel, dim3(1), dim3(1024), 0, s, *p, stats);
-    hipLaunchKernelGGL(rt_column_test_kernel, dim3((p->n_refs + 255u) / 256u), dim3(256), 0, s, *p, stats);
+    unsigned node_blocks = (p->n_nodes + 255u) / 256u;
+    const unsigned cap_blocks = (p->column_cap + 255u) / 256u;                 // the first kernel also clears the per-ray results
+    const unsigned first_grid = node_blocks > cap_blocks ? node_blocks : cap_blocks;
+    hipLaunchKernelGGL(rt_column_reach_max_kernel, dim3(first_grid), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(rt_column_reach_scan_kernel, dim3(1), dim3(1024), 0, s, *p, node_blocks);
+    hipLaunchKernelGGL(rt_column_reach_mark_kernel, dim3(node_blocks), dim3(256), 0, s, *p, stats);
+    hipLaunchKernelGGL(rt_column_filter_kernel, dim3((p->n_refs + 255u) / 256u), dim3(256), 0, s, *p, stats);
+    hipLaunchKernelGGL(rt_column_exact_kernel, dim3(2048), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 
