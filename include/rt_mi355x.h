@@ -86,12 +86,16 @@ typedef struct {
 } rt_kd_flat;
 
 /* Work counters; a ray is one TraceRay invocation (Renderer.cpp:154). nodes_visited / tris_tested are only
-   maintained while rt_set_stats(ctx, 1). */
-typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests; } rt_counters;
+   maintained while rt_set_stats(ctx, 1); in RT_ORDER_REFERENCE they equal what KDTreeCPU::intersect visits and tests
+   for the same rays.  prepass_nodes / prepass_tris are the part of those two sums that belongs to primary rays with
+   direction.x == +0, which a per-frame pre-pass resolves without walking the tree ray by ray: they are what the
+   reference's walk costs for those rays, not operations the GPU performed. */
+typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris; } rt_counters;
 
-/* Device time of the tracing kernels of a frame (the trace kernel, preceded for mesh scenes by the column pre-pass),
-   measured with HIP events on the stream they were launched on. */
-typedef struct { uint64_t launches; double total_ms; double last_ms; } rt_kernel_time;
+/* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
+   trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh
+   scenes whose camera has direction.x == +0 pixels. */
+typedef struct { uint64_t launches; double total_ms; double last_ms; double prepass_total_ms; } rt_kernel_time;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* Renderer::Renderer() (Renderer.cpp:16-18) on HIP device `device_id`. Returns NULL on failure. */
@@ -161,6 +165,11 @@ int rt_read_ray_dirs(rt_ctx*, float* out_xyz);
 int rt_set_stats(rt_ctx*, int on);
 int rt_read_counters(rt_ctx*, rt_counters* out);
 int rt_reset_counters(rt_ctx*);
+/* Diagnostics (only recorded while rt_set_stats(ctx, 1)): per wave of the last trace launch, 5 values: the 100 MHz device
+   clock at its start and end, the bounce-loop iterations it made, the sum over iterations of the busiest lane's node +
+   triangle steps, and the sum of all lanes' steps (their ratio / 64 = how evenly the lanes were loaded).  out holds
+   5 * max_waves values; the number of waves written is returned through *n_waves. */
+int rt_read_wave_clock(rt_ctx*, uint64_t* out, uint32_t max_waves, uint32_t* n_waves);
 int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
 int rt_reset_kernel_time(rt_ctx*);
 /* Device addresses (for collectives over the buffers): accumulation is width*height float4 (rgb + unused w),

@@ -20,7 +20,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_settings", "rt_set_spheres",
     "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_traversal_in_use", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
     "rt_render_frames", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_read_accum", "rt_set_record_ids",
-    "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters",
+    "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters", "rt_read_wave_clock",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_device_accum", "rt_device_image",
     "rt_host_camera_default_forward", "rt_host_camera_matrices", "rt_host_kd_build", "rt_host_kd_flat", "rt_host_kd_free",
 ]
@@ -39,11 +39,11 @@ class RtKdFlat(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("sphere_tests", C.c_uint64)]
+                ("sphere_tests", C.c_uint64), ("prepass_nodes", C.c_uint64), ("prepass_tris", C.c_uint64)]
 
 
 class RtKernelTime(C.Structure):
-    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("last_ms", C.c_double)]
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("last_ms", C.c_double), ("prepass_total_ms", C.c_double)]
 
 
 _lib = None
@@ -90,7 +90,7 @@ def lib():
         "rt_read_accum": ([vp, vp], C.c_int), "rt_set_record_ids": ([vp, C.c_int], C.c_int),
         "rt_read_primary_ids": ([vp, vp], C.c_int), "rt_read_ray_dirs": ([vp, vp], C.c_int),
         "rt_set_stats": ([vp, C.c_int], C.c_int), "rt_read_counters": ([vp, vp], C.c_int),
-        "rt_reset_counters": ([vp], C.c_int), "rt_get_kernel_time": ([vp, vp], C.c_int),
+        "rt_reset_counters": ([vp], C.c_int), "rt_read_wave_clock": ([vp, vp, u32, vp], C.c_int), "rt_get_kernel_time": ([vp, vp], C.c_int),
         "rt_reset_kernel_time": ([vp], C.c_int), "rt_device_accum": ([vp], vp), "rt_device_image": ([vp], vp),
         "rt_host_camera_default_forward": ([vp], None),
         "rt_host_camera_matrices": ([f32, f32, f32, u32, u32] + [vp] * 6, None),

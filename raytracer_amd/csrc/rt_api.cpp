@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -17,6 +18,7 @@
 
 extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, int ordered, unsigned grid, hipStream_t s);
 extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* blocks_per_cu);
+extern "C" unsigned rt_trace_block(int mode);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
@@ -51,7 +53,8 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     // ring of event pairs around the trace kernel: timing never makes the host wait for the launch it just made
     static const int EV_RING = 64;
-    hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {};
+    hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {}, ev_pre[EV_RING] = {};   // pre .. start = pre-pass, start .. stop = trace
+    bool ev_has_pre[EV_RING] = {};
     unsigned ev_head = 0, ev_tail = 0;               // [tail, head) are recorded and not yet read
     std::string error;
 
@@ -68,9 +71,10 @@ struct rt_ctx {
     std::vector<uint32_t> h_sphere_mat, h_tri_mat;
 
     DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image, d_dirs;
-    DevBuf<uint32_t> d_sphere_mat;
+    DevBuf<uint32_t> d_sphere_mat, d_work_heads;
     DevBuf<int32_t> d_ids;
-    DevBuf<unsigned long long> d_counters;
+    DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
+    uint32_t last_grid_waves = 0;
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
     bool use_host_dirs = false;          // d_dirs holds directions the host supplied (rt_set_ray_dirs)
     bool dirs_dirty = true;              // d_dirs must be regenerated from the camera before the next trace
@@ -91,7 +95,7 @@ struct rt_ctx {
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
-    rt_kernel_time ktime{0, 0.0, 0.0};
+    rt_kernel_time ktime{0, 0.0, 0.0, 0.0};
 };
 
 namespace {
@@ -145,7 +149,8 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.dirs = c->d_dirs.ptr; p.dirs_out = c->d_dirs.ptr;
     p.accum = c->d_accum.ptr; p.image = c->d_image.ptr;
     p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
-    p.counters = c->d_counters.ptr;
+    p.work_heads = c->d_work_heads.ptr;
+    p.counters = c->d_counters.ptr; p.wave_clock = c->d_wave_clock.ptr; p.column_stats = c->d_column_stats.ptr;
     p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
     p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
     p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr;
@@ -185,6 +190,10 @@ int collect_time(rt_ctx* c, bool all)
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
         c->ktime.launches++; c->ktime.total_ms += ms; c->ktime.last_ms = ms;
+        if (c->ev_has_pre[i]) {
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pre[i], c->ev_start[i]));
+            c->ktime.prepass_total_ms += ms;
+        }
         c->ev_tail++;
     }
     return RT_OK;
@@ -205,7 +214,8 @@ rt_ctx* rt_create(int device_id)
     DeviceGuard g(device_id);
     bool ok = g.ok && hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; ok && i < rt_ctx::EV_RING; ++i)
-        ok = hipEventCreate(&c->ev_start[i]) == hipSuccess && hipEventCreate(&c->ev_stop[i]) == hipSuccess;
+        ok = hipEventCreate(&c->ev_start[i]) == hipSuccess && hipEventCreate(&c->ev_stop[i]) == hipSuccess &&
+             hipEventCreate(&c->ev_pre[i]) == hipSuccess;
     if (!ok) {
         fail(nullptr, RT_E_HIP, "stream/event creation failed on device %d", device_id);
         rt_destroy(c); return nullptr;
@@ -215,6 +225,11 @@ rt_ctx* rt_create(int device_id)
     if (hipGetDeviceProperties(&prop, device_id) != hipSuccess || prop.multiProcessorCount <= 0 ||
         c->d_counters.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * 4) != hipSuccess ||
         hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_wave_clock.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * RT_WAVE_CLOCK_WORDS) != hipSuccess ||
+        hipMemset(c->d_wave_clock.ptr, 0, c->d_wave_clock.count * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
+        hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
+        c->d_column_stats.resize(2) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 16) != hipSuccess ||
         c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
         c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
         c->d_column_dirs.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_queue_count.resize(1) != hipSuccess ||
@@ -235,12 +250,13 @@ void rt_destroy(rt_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_spheres.release(); c->d_materials.release(); c->d_nodes.release(); c->d_leafrecs.release();
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
-    c->d_dirs.release(); c->d_ids.release(); c->d_counters.release();
+    c->d_dirs.release(); c->d_ids.release(); c->d_counters.release(); c->d_wave_clock.release(); c->d_column_stats.release(); c->d_work_heads.release();
     c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
     c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
+        if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -442,7 +458,9 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
         const float* chi = low_is_left[n] ? cr : cl; const float* ehi = low_is_left[n] ? er : el;
         for (int a = 0; a < 3 && partition; ++a) {
             if (a != axis) { partition = cl[a] == cn[a] && cr[a] == cn[a] && el[a] == en[a] && er[a] == en[a]; continue; }
-            const float tol = 1e-4f * en[a] + 1e-30f;
+            // the builder forms the child boxes with a few roundings at the magnitude of the coordinates themselves
+            const float mag = (cn[a] < 0.0f ? -cn[a] : cn[a]) + en[a];
+            const float tol = 1e-5f * mag + 1e-30f;
             const float lo = cn[a] - en[a], hi = cn[a] + en[a];
             auto near = [tol](float x, float y) { return (x < y ? y - x : x - y) <= tol; };
             partition = near(clo[a] - elo[a], lo) && near(chi[a] + ehi[a], hi) && near(clo[a] + elo[a], chi[a] - ehi[a]);
@@ -571,9 +589,15 @@ int trace_grid(rt_ctx* c, int mode, bool stats, bool ordered, uint32_t n_units, 
         int q = 0;
         HIP_TRY(c, rt_trace_occupancy(mode, stats ? 1 : 0, ordered ? 1 : 0, &q));
         per_cu = q < 1 ? 1 : (q > (int)kMaxBlocksPerCu ? (int)kMaxBlocksPerCu : q);
+        // tuning knob: RT_TRACE_BLOCKS_PER_CU=<n> overrides the occupancy query (units are pulled dynamically, so any grid is correct)
+        // (never beyond 32 waves per CU: the per-wave counter slots are sized for that)
+        const int max_blocks = 32 / (int)(rt_trace_block(mode) / 64u);
+        if (const char* e = getenv("RT_TRACE_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= max_blocks) per_cu = v; }
+        if (per_cu > max_blocks) per_cu = max_blocks;
     }
     grid = (unsigned)c->n_cus * (unsigned)per_cu;
-    const unsigned by_work = (n_units * RT_UNIT / 64u + 3) / 4;      // a wave per 64 pixels is the most that can help
+    const unsigned waves_per_block = rt_trace_block(mode) / 64u;
+    const unsigned by_work = (n_units * RT_UNIT / 64u + waves_per_block - 1) / waves_per_block;   // a wave per 64 pixels is the most that can help
     if (grid > by_work) grid = by_work;
     if (grid == 0) grid = 1;
     return RT_OK;
@@ -600,12 +624,15 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     const bool ordered = mode != RT_SCENE_SPHERES && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units, grid)) return rc;
-    // the event pair brackets the tracing kernels of the frame: the column pre-pass (mesh scenes whose camera has
-    // direction.x == +0 pixels) and the trace kernel
+    // events: [pre, start) = the column pre-pass (mesh scenes whose camera has direction.x == +0 pixels), [start, stop) = the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
+    c->ev_has_pre[ev] = mode != RT_SCENE_SPHERES && c->n_columns;
+    if (c->ev_has_pre[ev]) {
+        HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
+        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
+    } else p.column_best = nullptr;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
-    if (mode != RT_SCENE_SPHERES && c->n_columns) HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
-    else p.column_best = nullptr;
+    c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
@@ -708,6 +735,10 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     for (size_t i = 0; i < h.size(); i += 4) {
         out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
     }
+    unsigned long long cs[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
+    out->prepass_nodes = cs[0]; out->prepass_tris = cs[1];
+    out->nodes_visited += cs[0]; out->tris_tested += cs[1];
     return RT_OK;
 }
 
@@ -717,6 +748,19 @@ int rt_reset_counters(rt_ctx* c)
     if (!c->d_counters.count) return RT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 2 * sizeof(unsigned long long), c->stream));
+    return RT_OK;
+}
+
+int rt_read_wave_clock(rt_ctx* c, uint64_t* out, uint32_t max_waves, uint32_t* n_waves)
+{
+    if (!c || !out || !n_waves) return RT_E_ARG;
+    DeviceGuard g(c->device);
+    if (int rc = rt_sync(c)) return rc;
+    uint32_t n = c->last_grid_waves < max_waves ? c->last_grid_waves : max_waves;
+    if ((size_t)n * RT_WAVE_CLOCK_WORDS > c->d_wave_clock.count) n = (uint32_t)(c->d_wave_clock.count / RT_WAVE_CLOCK_WORDS);
+    if (n) HIP_TRY(c, hipMemcpy(out, c->d_wave_clock.ptr, (size_t)n * RT_WAVE_CLOCK_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *n_waves = n;
     return RT_OK;
 }
 
@@ -734,7 +778,7 @@ int rt_reset_kernel_time(rt_ctx* c)
     if (!c) return RT_E_ARG;
     DeviceGuard g(c->device);
     if (int rc = collect_time(c, true)) return rc;
-    c->ktime = rt_kernel_time{0, 0.0, 0.0};
+    c->ktime = rt_kernel_time{0, 0.0, 0.0, 0.0};
     return RT_OK;
 }
 

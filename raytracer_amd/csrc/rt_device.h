@@ -9,8 +9,14 @@
 #define RT_MODE_SPHERES 1
 #define RT_MODE_BOTH    2
 
-#define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile; units are dealt to waves round-robin
+#define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile
+#define RT_SPHERE_BLOCK 1024       // threads per workgroup of the sphere-scene trace kernel (16 waves sharing one unit counter in LDS)
+#define RT_WAVE_CLOCK_WORDS 5
+#define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
+#define RT_HEAD_STRIDE 32          // words between heads
 #define RT_INLINE_SPHERES 32       // spheres carried in the kernel arguments (scalar loads); more go through HBM
+#define RT_LDS_SPHERES 128         // scenes with at most this many spheres and materials keep them in LDS for the per-lane
+#define RT_LDS_MATERIALS 128       // lookups of the closest hit (a few KB per workgroup); larger scenes read them from HBM
 
 #define RT_LEAF_INTERIOR (-1)      // RtNode.leaf_first: not a leaf
 #define RT_LEAF_EMPTY    (-2)      // a leaf that owns no triangle
@@ -48,6 +54,7 @@ struct RtParams {
     uint32_t n_nodes;
     uint32_t band_index, band_count;       // screen-tile split: this context renders bands b*band_count + band_index
     uint32_t tile_rows, n_units;           // 8-row tile rows / RT_UNIT-pixel work units in the bands this context renders
+    uint32_t* work_heads;                  // RT_WORK_HEADS ticket counters (RT_HEAD_STRIDE words apart), zero before every trace launch
     int32_t  use_ace;
     const float4* spheres;
     const uint32_t* sphere_mat;
@@ -61,6 +68,9 @@ struct RtParams {
     float4* image;
     int32_t* primary_ids;                   // optional
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
+    unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave (counting kernels only): start, end (100 MHz clock), loop
+                                            // iterations, sum over iterations of the busiest lane's node + triangle steps, sum of all lanes' steps
+    unsigned long long* column_stats;       // 2: nodes / triangles the reference's walk spends on the column rays
     // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records
     uint32_t  column_cap;

@@ -204,8 +204,11 @@ __device__ __forceinline__ void trace_spheres_from(const RtParams& p, F3 O, F3 D
     float four_a = 4.0f * a;
     float best_num = __builtin_inff();
     const uint32_t n = p.n_spheres;
+    if (n == 0u) return;
+    float4 next = INLINE ? p.sph_inline[0] : p.spheres[0];              // wave-uniform index: a scalar load
     for (uint32_t i = 0; i < n; ++i) {
-        const float4 cur = INLINE ? p.sph_inline[i] : p.spheres[i];     // wave-uniform index
+        const float4 cur = next;
+        if (i + 1u < n) next = INLINE ? p.sph_inline[i + 1u] : p.spheres[i + 1u];   // in flight while this sphere is tested
         F3 ro = O - f3(cur.x, cur.y, cur.z);
         float b = 2.0f * dot3(ro, D);
         float c = dot3(ro, ro) - cur.w;                    // cur.w = radius*radius, rounded once at upload
@@ -423,10 +426,25 @@ __device__ __forceinline__ void path_begin(Path& s, const RtParams& p, uint32_t 
     s.column_slot = __float_as_uint(d.w);
 }
 
+// Where the closest-hit lookups (sphere centre and material by per-lane index) read from: a copy in LDS when the scene is
+// small enough (every scene of the reference application is), else HBM.
+struct SceneLds {
+    float4 spheres[RT_LDS_SPHERES];
+    uint32_t sphere_mat[RT_LDS_SPHERES];
+    float4 materials[3 * RT_LDS_MATERIALS];
+};
+
+// All threads of the workgroup call this once before tracing (the host picks the LDS variant only for scenes that fit).
+__device__ __forceinline__ void stage_scene(const RtParams& p, SceneLds& lds)
+{
+    for (uint32_t i = threadIdx.x; i < p.n_spheres; i += blockDim.x) { lds.spheres[i] = p.spheres[i]; lds.sphere_mat[i] = p.sphere_mat[i]; }
+    for (uint32_t i = threadIdx.x; i < 3u * p.n_materials; i += blockDim.x) lds.materials[i] = p.materials[i];
+}
+
 // One iteration of the bounce loop (Renderer.cpp:149-226).  Returns true when the path has ended (miss, roulette, or the
 // bounce budget is used up).
-template <int MODE, bool STATS, bool ORDERED>
-__device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* primary_id, bool have_mesh_hit, Hit mesh_hit,
+template <int MODE, bool STATS, bool ORDERED, bool in_lds>
+__device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const SceneLds& lds, int32_t* primary_id, bool have_mesh_hit, Hit mesh_hit,
                                           uint32_t& n_rays, uint32_t& n_nodes, uint32_t& n_tris)
 {
     if (s.bounce >= p.bounces) return true;                // "for (i = 0; i < Bounces; i++)" with Bounces == 0
@@ -455,11 +473,11 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* p
     }
     F3 P, N;
     uint32_t matIndex;
-    if (tS < th.t) {                                        // ClosestHitSphere (Renderer.cpp:303-317)
-        const float4 sp = p.spheres[iS];                  // per-lane index: vector load
+    if (MODE == RT_MODE_SPHERES || tS < th.t) {             // ClosestHitSphere (Renderer.cpp:303-317); a sphere hit has t < FLT_MAX
+        const float4 sp = in_lds ? lds.spheres[iS] : p.spheres[iS];      // per-lane index
         P = O + D * tS;
         N = normalize3(P - f3(sp.x, sp.y, sp.z));
-        matIndex = p.sphere_mat[iS];
+        matIndex = in_lds ? lds.sphere_mat[iS] : p.sphere_mat[iS];
         if (primary_id && first) *primary_id = iS;
     } else {                                                // ClosestHitTriangle (Renderer.cpp:319-332)
         const float4* sh = p.trishade + 3 * (size_t)th.id;
@@ -471,14 +489,14 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* p
         if (primary_id && first) *primary_id = RT_ID_TRI_BIT | th.id;
     }
 
-    const float4 m0 = p.materials[3 * matIndex];           // albedo.rgb, roughness
-    const float4 m1 = p.materials[3 * matIndex + 1];       // emission.rgb, transparency
+    const float4 m0 = in_lds ? lds.materials[3 * matIndex] : p.materials[3 * matIndex];             // albedo.rgb, roughness
+    const float4 m1 = in_lds ? lds.materials[3 * matIndex + 1] : p.materials[3 * matIndex + 1];     // emission.rgb, transparency
     bool hitInside = dot3(D, N) > 0.0f;
     F3 normalSurface = hitInside ? -N : N;
     s.O = P + normalSurface * EPSILON;
 
     if (m1.w > 0.0f) {                                      // always transmit (Renderer.cpp:176-197)
-        const float IOR = p.materials[3 * matIndex + 2].x;
+        const float IOR = in_lds ? lds.materials[3 * matIndex + 2].x : p.materials[3 * matIndex + 2].x;
         // RefractionRay (Renderer.cpp:334-361)
         F3 ref_n = N;
         float eta_t = IOR, eta_i = 1.0f;
@@ -509,8 +527,7 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, int32_t* p
 }
 
 // Pixel `slot` of work unit `unit`: units are the four 8x2 strips of each 8x8 tile of the 16-row bands this context
-// renders; tiles are numbered down the columns, so the pixels of one image column (the default camera's centre column is the
-// expensive one for meshes) fall into consecutive units and therefore onto different waves.
+// renders; tiles are numbered down the columns of tiles.
 __device__ __forceinline__ bool unit_pixel(const RtParams& p, uint32_t unit, uint32_t slot, uint32_t& pixel)
 {
     const uint32_t tile = unit >> 2;
@@ -793,7 +810,7 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.column_flags, 1u);
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(__ballot(visited));
-        if (lane == 0u && n) atomicAdd(&p.counters[1], (unsigned long long)n * count);     // every column ray visits these nodes
+        if (lane == 0u && n) atomicAdd(&p.column_stats[0], (unsigned long long)n * count);  // every column ray visits these nodes
     }
 }
 
@@ -813,7 +830,7 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
     const unsigned long long any = __ballot(use);
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(any);
-        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.counters[2], (unsigned long long)n * count);   // the tests the reference makes
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * count);   // the tests the reference makes
     }
     if (!use) return;
     const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
@@ -865,20 +882,44 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
     }
 }
 
-// The trace kernel is persistent: the grid is sized to what the chip holds at once and every wave walks its own list of
-// pixel tiles.  Each loop iteration advances every live lane by one bounce; lanes whose path ended take the next
-// (pixel, frame) before the next iteration, so the wave stays full until its list runs dry.  A lane keeps its pixel for all
-// n_frames frames and adds them in frame order, which makes the sum identical to n_frames separate Render calls.
-// The frame's RT_UNIT-pixel units are dealt round-robin over the waves (no shared counter: one atomic word serves only ~88
-// requests per microsecond, too few for a 0.2 ms frame), so every wave gets the same number of units to within one.
-template <int MODE, bool STATS, bool ORDERED>
-__global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
+// The trace kernels are persistent: the grid is sized to what the chip holds at once and every wave works through 16-pixel
+// units (the four 8x2 strips of each 8x8 tile).  Each loop iteration advances every live lane by one bounce; lanes whose path
+// ended take the next (pixel, frame) before the next iteration, so the wave stays full until the frame runs dry.  A lane keeps
+// its pixel for all n_frames frames and adds them in frame order, which makes the sum identical to n_frames separate Render
+// calls.  How units reach the waves depends on the scene:
+//   spheres only : every region of the image costs about the same, so each workgroup owns a fixed share of the units (workgroup b
+//                  takes units b, b + workgroups, ...) and its 16 waves draw them from a counter in LDS.  The waves of a SIMD do
+//                  not advance at the same rate (the oldest wave is served first), so a fixed share per WAVE leaves each SIMD
+//                  half empty for the last third of the frame; the LDS counter costs ~100 cycles per unit and lets all waves of a
+//                  workgroup finish together.  A global ticket per unit would cost more than it balances here: vector memory
+//                  operations complete in order, so every later load of the wave also waits for the atomic's return.
+//   tree scenes  : a unit's cost varies by orders of magnitude (a primary ray that misses the mesh's box against eight bounces
+//                  through the tree), so units are pulled from RT_WORK_HEADS ticket counters.  Each head owns every 8th unit;
+//                  a wave draws from the head of its workgroup number modulo 8 (workgroups are dealt round-robin over the
+//                  XCDs: one head per XCD) and moves on to the other heads when its own is exhausted.  Units are taken whole,
+//                  one per 16 idle lanes and all of a refill with one atomic, so a wave never owns pixels it cannot start at
+//                  once -- otherwise the last units trickle through a few lanes of one wave while the rest of the chip idles.
+__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h) { return (p.n_units + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS; }
+
+template <int MODE, bool STATS, bool ORDERED, bool LDS_SCENE>
+__device__ __forceinline__ void trace_body(const RtParams& p)
 {
+    constexpr bool DYNAMIC = MODE != RT_MODE_SPHERES;
+    __shared__ SceneLds lds;                                // only allocated where LDS_SCENE variants use it
+    __shared__ uint32_t wg_next;                            // spheres: how many of this workgroup's units have been handed out
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t n_waves = gridDim.x * 4u;
-    uint32_t unit = wave, slot = 0;                         // wave-uniform: current work unit (wave, wave + n_waves, ...) and its first free pixel
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (threadIdx.x == 0) wg_next = 0u;
+    if (LDS_SCENE) stage_scene(p, lds);
+    __syncthreads();
+    // wave-uniform.  Workgroup share: current unit and its first free pixel (RT_UNIT = used up).  Tickets: the head drawn from,
+    // heads found empty.
+    uint32_t unit = 0, slot = RT_UNIT;
+    bool share_done = false;
+    uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
+    unsigned long long clock_start = 0, steps_max_sum = 0, steps_sum = 0; uint32_t n_iterations = 0;
+    if (STATS) clock_start = __builtin_amdgcn_s_memrealtime();
 
     bool live = false;
     uint32_t pixel = 0, frame = 0;
@@ -887,24 +928,55 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
 
     for (;;) {
-        // ---- give every idle lane a pixel while this wave has units left
+        // ---- give idle lanes pixels while there are units left
         unsigned long long need = __ballot(!live);
-        while (need != 0ull && unit < p.n_units) {
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            const uint32_t avail = RT_UNIT - slot;
-            if (!live && rank < avail && unit_pixel(p, unit, slot + rank, pixel)) {
-                live = true;
-                frame = 0;
-                acc = f3(0.0f, 0.0f, 0.0f);                 // frame index 1 restarts accumulation (Renderer.cpp:55-56)
-                if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
-                path_begin(s, p, pixel, p.frame_first);
+        if (DYNAMIC) {
+            uint32_t want = (uint32_t)__popcll(need) / RT_UNIT;
+            while (want != 0u && heads_empty < RT_WORK_HEADS) {
+                const uint32_t count = head_count(p, head);
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(p.work_heads + head * RT_HEAD_STRIDE, want);
+                t = __builtin_amdgcn_readfirstlane(t);
+                const uint32_t got = t < count ? (want < count - t ? want : count - t) : 0u;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                // ticket t of head h is unit h + 8 t; idle lane number `rank` takes pixel rank % 16 of the rank / 16-th unit taken
+                if (!live && rank < got * RT_UNIT && unit_pixel(p, head + RT_WORK_HEADS * (t + rank / RT_UNIT), rank % RT_UNIT, pixel)) {
+                    live = true;
+                    frame = 0;
+                    acc = f3(0.0f, 0.0f, 0.0f);             // frame index 1 restarts accumulation (Renderer.cpp:55-56)
+                    if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+                    path_begin(s, p, pixel, p.frame_first);
+                }
+                if (got < want) { heads_empty++; head = (head + 1u) % RT_WORK_HEADS; }
+                need = __ballot(!live);                     // what is still idle: lanes without a unit, and pixels outside the frame
+                want = (uint32_t)__popcll(need) / RT_UNIT;
             }
-            const uint32_t wanted = (uint32_t)__popcll(need);
-            slot += wanted < avail ? wanted : avail;
-            if (slot == RT_UNIT) { unit += n_waves; slot = 0; }
-            need = __ballot(!live);                         // lanes beyond this unit, and lanes whose pixel fell outside the frame
+        } else {
+            while (need != 0ull && !share_done) {
+                if (slot == RT_UNIT) {                      // next unit of the workgroup's share
+                    uint32_t k = 0;
+                    if (lane == 0) k = atomicAdd(&wg_next, 1u);
+                    k = __builtin_amdgcn_readfirstlane(k);
+                    unit = blockIdx.x + gridDim.x * k;
+                    if (unit >= p.n_units) { share_done = true; break; }
+                    slot = 0;
+                }
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const uint32_t avail = RT_UNIT - slot;
+                if (!live && rank < avail && unit_pixel(p, unit, slot + rank, pixel)) {
+                    live = true;
+                    frame = 0;
+                    acc = f3(0.0f, 0.0f, 0.0f);
+                    if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+                    path_begin(s, p, pixel, p.frame_first);
+                }
+                const uint32_t wanted = (uint32_t)__popcll(need);
+                slot += wanted < avail ? wanted : avail;
+                need = __ballot(!live);                     // lanes beyond this unit, and lanes whose pixel fell outside the frame
+            }
         }
         if (__ballot(live) == 0ull) break;                  // nothing in flight and nothing left to take
+        if (STATS) n_iterations++;
 
         // ---- rays the tree cannot prune (a zero direction component): the wave walks the tree for them, one at a time
         bool have_mesh_hit = false;
@@ -942,9 +1014,13 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
         }
 
         // ---- one bounce for every lane with a path
+        uint32_t lane_steps = 0;
         if (live) {
             int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
-            if (path_step<MODE, STATS, ORDERED>(s, p, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris)) {
+            const uint32_t steps_before = n_nodes + n_tris;
+            const bool ended = path_step<MODE, STATS, ORDERED, LDS_SCENE>(s, p, lds, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris);
+            if (STATS) lane_steps = n_nodes + n_tris - steps_before;
+            if (ended) {
                 if (id_out && p.bounces == 0) *id_out = -1;
                 acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
                 frame++;
@@ -952,8 +1028,21 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
                 else { p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f); live = false; }
             }
         }
+        if (STATS) {                                        // how unevenly the lanes of this iteration were loaded
+            uint32_t mx = lane_steps, sm = lane_steps;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o;
+                sm += __shfl_xor(sm, off);
+            }
+            steps_max_sum += mx; steps_sum += sm;
+        }
     }
 
+    if (STATS && p.wave_clock && lane == 0) {
+        unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
+        wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
+        wc[3] = steps_max_sum; wc[4] = steps_sum;
+    }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
         unsigned long long* slot = p.counters + 4 * (size_t)wave;
@@ -969,6 +1058,22 @@ __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
     }
 }
 
+// Sphere frames: workgroups of 16 waves, two per CU, and at most 80 scalar registers so that the chip admits the full 32 waves
+// per CU (above 80 it silently admits fewer than the occupancy query promises, and the surplus workgroups of a persistent grid
+// only start when others have finished).
+template <bool STATS, bool LDS_SCENE>
+__global__ __launch_bounds__(RT_SPHERE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void rt_trace_spheres_kernel(RtParams p)
+{
+    trace_body<RT_MODE_SPHERES, STATS, false, LDS_SCENE>(p);
+}
+
+template <int MODE, bool STATS, bool ORDERED>
+__global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
+{
+    // tree scenes keep the closest-hit lookups in HBM: these kernels are bound by registers (waves per SIMD), not by those loads
+    trace_body<MODE, STATS, ORDERED, false>(p);
+}
+
 // Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
 __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t frame_index)
 {
@@ -976,12 +1081,15 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t fr
     const uint32_t x = blockIdx.x * RT_TILE + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t band = blockIdx.y * p.band_count + p.band_index;
     const uint32_t y = band * RT_TILE + (wave >> 1) * 8u + (lane >> 3);
+    // the trace kernel that produced this frame has drained the unit queue: zero its heads for the next trace launch
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
     if (x < p.width && y < p.height) {
         const uint32_t pixel = y * p.width + x;
         float4 a = p.accum[pixel];
         p.image[pixel] = resolve_px(f3(a.x, a.y, a.z), (float)frame_index, p.use_ace);
     }
 }
+
 
 // Anti-alias filter (Renderer.cpp:84-124): 3x3 window, taps with |xo + yo| > 1 skipped, weight 1 - (|xo| + |yo|) / 2
 // (so the two anti-diagonal taps carry weight 0 but still take part), on the raw accumulation; overwrites the image.
@@ -1009,18 +1117,21 @@ __global__ __launch_bounds__(256) void rt_aa_kernel(RtParams p, uint32_t frame_i
 }
 
 // ---- launchers (called from rt_api.cpp) -----------------------------------------------------------------------------
-// Dispatch over (mode, stats, ordered); sphere-only frames have no tree to order.
+// Dispatch over (mode, stats, ordered); sphere-only frames have no tree to order, and keep spheres + materials in LDS when
+// there are few enough of them (`small_scene`).
 template <class F>
-static hipError_t for_variant(int mode, int stats, int ordered, F&& f)
+static hipError_t for_variant(int mode, int stats, int ordered, int small_scene, F&& f)
 {
+    if (mode == RT_MODE_SPHERES) {
+        if (small_scene) return stats ? f(rt_trace_spheres_kernel<true, true>) : f(rt_trace_spheres_kernel<false, true>);
+        return stats ? f(rt_trace_spheres_kernel<true, false>) : f(rt_trace_spheres_kernel<false, false>);
+    }
     const int key = (mode * 2 + (stats ? 1 : 0)) * 2 + ((ordered && mode != RT_MODE_SPHERES) ? 1 : 0);
     switch (key) {
     case 0:  return f(rt_trace_kernel<RT_MODE_MESH, false, false>);
     case 1:  return f(rt_trace_kernel<RT_MODE_MESH, false, true>);
     case 2:  return f(rt_trace_kernel<RT_MODE_MESH, true, false>);
     case 3:  return f(rt_trace_kernel<RT_MODE_MESH, true, true>);
-    case 4:  return f(rt_trace_kernel<RT_MODE_SPHERES, false, false>);
-    case 6:  return f(rt_trace_kernel<RT_MODE_SPHERES, true, false>);
     case 8:  return f(rt_trace_kernel<RT_MODE_BOTH, false, false>);
     case 9:  return f(rt_trace_kernel<RT_MODE_BOTH, false, true>);
     case 10: return f(rt_trace_kernel<RT_MODE_BOTH, true, false>);
@@ -1030,17 +1141,21 @@ static hipError_t for_variant(int mode, int stats, int ordered, F&& f)
 }
 
 // Resident workgroups per CU of the trace kernel variant: sizes the persistent grid.
+// Threads per workgroup of the variant.
+extern "C" unsigned rt_trace_block(int mode) { return mode == RT_MODE_SPHERES ? RT_SPHERE_BLOCK : 256u; }
+
 extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* blocks_per_cu)
 {
-    return for_variant(mode, stats, ordered, [&](auto kernel) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, 256, 0);
+    return for_variant(mode, stats, ordered, 1, [&](auto kernel) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kernel, (int)rt_trace_block(mode), 0);
     });
 }
 
 extern "C" hipError_t rt_launch_trace(const RtParams* p, int mode, int stats, int ordered, unsigned grid, hipStream_t s)
 {
-    return for_variant(mode, stats, ordered, [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, *p);
+    const int small_scene = p->n_spheres <= RT_LDS_SPHERES && p->n_materials <= RT_LDS_MATERIALS;
+    return for_variant(mode, stats, ordered, small_scene, [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(rt_trace_block(mode)), 0, s, *p);
         return hipGetLastError();
     });
 }

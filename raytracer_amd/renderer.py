@@ -301,6 +301,14 @@ class Renderer:
         check(self._h, self._L.rt_read_counters(self._h, C.byref(c)), "rt_read_counters")
         return c
 
+    def read_wave_clock(self, max_waves=16384):
+        """(n, 5) uint64 per wave of the last trace launch made with set_stats(True): start, end (100 MHz ticks), iterations,
+        sum over iterations of the busiest lane's steps, sum of all lanes' steps."""
+        out = np.zeros((max_waves, 5), np.uint64)
+        n = C.c_uint32()
+        check(self._h, self._L.rt_read_wave_clock(self._h, ptr(out), max_waves, C.byref(n)), "rt_read_wave_clock")
+        return out[:n.value]
+
     def reset_counters(self):
         check(self._h, self._L.rt_reset_counters(self._h), "rt_reset_counters")
 

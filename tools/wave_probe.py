@@ -1,0 +1,46 @@
+"""Probe: per-wave start/end clocks and loop iterations of the persistent trace kernel (counting variant), to see how evenly
+the waves of one frame finish.  python tools/wave_probe.py <config>"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+import bench
+
+cfgno = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+cfg = bench.CONFIGS[cfgno]
+scene = bench.build_scene(cfg)
+w, h = cfg["w"], cfg["h"]
+cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+r = rt.Renderer(0); r.download = False
+st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
+r.OnResize(w, h); r.upload(scene, cam)
+for f in range(1, 4):
+    r.render_only(f)
+r.set_stats(True); r.reset_counters()
+r.render_only(4); r.sync()
+c = r.read_counters()
+wc = r.read_wave_clock().astype(np.float64)
+start, end, it = wc[:, 0], wc[:, 1], wc[:, 2]
+t0 = start.min()
+span = (end.max() - t0) * 0.01
+dur = (end - start) * 0.01
+q = lambda a: "min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % tuple(np.percentile(a, [0, 10, 50, 90, 100]))
+print("config %d: %d waves, kernel span %.1f us, rays %d" % (cfgno, len(wc), span, c.rays))
+print("  wave start offset us :", q((start - t0) * 0.01))
+print("  wave end offset us   :", q((end - t0) * 0.01))
+print("  wave duration us     :", q(dur))
+print("  iterations           :", q(it))
+print("  mean busy fraction (sum of wave durations / (waves x span)): %.3f" % (dur.sum() / (len(wc) * span)))
+print("  lane-steps per iteration (rays / sum iterations): %.1f of 64" % (c.rays / it.sum()))
+order = np.argsort(-end)
+print("  last waves to finish (end us, duration us, iterations):", [(round((end[i] - t0) * 0.01, 1), round(dur[i], 1), int(it[i])) for i in order[:12]])
+per_it = dur / np.maximum(it, 1)
+print("  us per iteration     :", q(per_it))
+late = end > t0 + 0.5 * (end.max() - t0)
+print("  waves still running after half the span: %d of %d; their iterations: %s" % (late.sum(), len(wc), q(it[late])))
+if wc.shape[1] >= 5 and wc[:, 3].sum() > 0:
+    mx, sm = wc[:, 3], wc[:, 4]
+    print("  traversal steps: lane balance over the frame = %.3f (all lanes' steps / (64 x busiest lane's steps, summed over iterations))" % (sm.sum() / (64 * mx.sum())))
+    print("  busiest-lane steps per iteration:", q(mx / np.maximum(it, 1)))
+    print("  the 12 last waves: busiest-lane steps/iteration, balance:", [(int(mx[i] / max(it[i], 1)), round(sm[i] / (64 * max(mx[i], 1)), 2)) for i in order[:12]])
+    print("  us per busiest-lane step (wave duration / sum of busiest-lane steps):", q(dur / np.maximum(mx, 1)))
