@@ -204,7 +204,7 @@ def main():
             roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": _traffic_from_profile(args.config),
                     "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
-                    "kernel": "rt_trace_kernel<spheres>", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+                    "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
                     "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
                     "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path"}
         else:
@@ -221,24 +221,31 @@ def main():
                 for f in frames[:4]:
                     r.render_only(f)
                 c3 = r.read_counters()
-                ref_counts = {"nodes_per_ray": c3.nodes_visited / max(c3.rays, 1), "tris_per_ray": c3.tris_tested / max(c3.rays, 1)}
+                ref_counts = {"nodes_per_ray": (c3.nodes_visited - c3.prepass_nodes) / max(c3.rays, 1),
+                              "tris_per_ray": (c3.tris_tested - c3.prepass_tris) / max(c3.rays, 1)}
                 st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
             r.set_stats(False)
             per_launch = lambda v: v / max(len(frames), 1)
-            bytes_ = (per_launch(c2.nodes_visited) * BYTES_PER_NODE + per_launch(c2.tris_tested) * BYTES_PER_TRI
-                      + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
+            # what the trace kernel itself walked: the counters minus the part that stands for the column rays (primary rays with
+            # direction.x == +0), which the pre-pass resolves without walking the tree ray by ray
+            own_nodes = per_launch(c2.nodes_visited - c2.prepass_nodes)
+            own_tris = per_launch(c2.tris_tested - c2.prepass_tris)
+            bytes_ = (own_nodes * BYTES_PER_NODE + own_tris * BYTES_PER_TRI + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
             achieved = bytes_ / avg_kernel_s / 1e9
+            small = cfg["mesh"][1] < 1000
             roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                     "traffic": _traffic_from_profile(args.config),
-                    "kernel": "rt_column_reach_kernel + rt_column_test_kernel + rt_trace_kernel<%s> (one event pair around the three)"
-                              % ("mesh" if cfg["mode"] == 0 else "both"),
+                    "kernel": "rt_trace_kernel<%s, %s>" % ("mesh" if cfg["mode"] == 0 else "spheres+mesh", order_used),
                     "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
-                    "nodes_per_ray": c2.nodes_visited / max(c2.rays, 1), "tris_per_ray": c2.tris_tested / max(c2.rays, 1),
+                    "prepass_avg_ms": kt.prepass_total_ms / max(kt.launches, 1),
+                    "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
+                    "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
                     "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
-                    "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested (+40 B per hit, +40 B per pixel) "
-                            "with the node / triangle counts of the walk order that was timed (device counters); "
-                            + ("tree + leaf records (20 MB) sit in L2 / Infinity Cache at this size, so this is cache traffic, not HBM"
-                               if cfg["mesh"][1] < 1000 else "tree + leaf records are ~2.7 GB: HBM-resident random access")}
+                    "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
+                            "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
+                            "that was timed; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "
+                            + ("nodes (8 x 3.6 MB) + leaf records (17 MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
+                               else "nodes (8 x 0.5 GB) + leaf records (2.4 GB) are HBM-resident: random 32-48 B reads")}
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,

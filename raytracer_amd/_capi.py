@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librt_mi355x.so")
+# RT_MI355X_LIB=<path> loads another build of the same library (kernel experiments); the default is the in-tree build
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(_HERE, "lib", "librt_mi355x.so")
 
 RT_OK = 0
 SCENE_MESH, SCENE_SPHERES, SCENE_BOTH = 0, 1, 2

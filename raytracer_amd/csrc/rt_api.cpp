@@ -63,7 +63,7 @@ struct rt_ctx {
     bool have_camera = false;
     float cam_pos[3]{}, inv_proj[16]{}, inv_view[16]{};
     uint32_t band_index = 0, band_count = 1;
-    bool record_ids = false, stats = false;
+    bool record_ids = false, stats = false, wave_clock_on = false;
 
     uint32_t n_spheres = 0, n_materials = 0, n_nodes = 0, n_tris = 0, n_verts = 0;
     std::vector<float> h_verts;           // kept for the tree re-layout
@@ -150,7 +150,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.accum = c->d_accum.ptr; p.image = c->d_image.ptr;
     p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
     p.work_heads = c->d_work_heads.ptr;
-    p.counters = c->d_counters.ptr; p.wave_clock = c->d_wave_clock.ptr; p.column_stats = c->d_column_stats.ptr;
+    p.counters = c->d_counters.ptr; p.wave_clock = c->wave_clock_on ? c->d_wave_clock.ptr : nullptr; p.column_stats = c->d_column_stats.ptr;
     p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
     p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
     p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr;
@@ -721,7 +721,7 @@ int rt_read_ray_dirs(rt_ctx* c, float* out_xyz)
     return RT_OK;
 }
 
-int rt_set_stats(rt_ctx* c, int on) { if (!c) return RT_E_ARG; c->stats = on != 0; return RT_OK; }
+int rt_set_stats(rt_ctx* c, int on) { if (!c) return RT_E_ARG; c->stats = (on & 1) != 0; c->wave_clock_on = (on & 2) != 0; return RT_OK; }
 
 int rt_read_counters(rt_ctx* c, rt_counters* out)
 {

@@ -11,6 +11,7 @@
 
 #define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile
 #define RT_SPHERE_BLOCK 1024       // threads per workgroup of the sphere-scene trace kernel (16 waves sharing one unit counter in LDS)
+#define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
 #define RT_WAVE_CLOCK_WORDS 5
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
 #define RT_HEAD_STRIDE 32          // words between heads

@@ -32,8 +32,29 @@ __device__ __forceinline__ F3 cross3(F3 x, F3 y)
 {
     return f3(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y);
 }
+// Correctly rounded square root, bit for bit sqrtf.  For x in [2^-96, FLT_MAX] it is the core of the compiler's own expansion
+// of sqrtf -- the hardware estimate (within one ulp), then the neighbours one ulp below and above tried with exact FMA
+// residuals -- without the rescaling that only smaller inputs need and without the zero / infinity / NaN pass-through; any
+// other input takes sqrtf itself.  The path calls this 14 times per bounce; the plain expansion is twice as long.
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+    float r = (0.0f >= r_below) ? below : s;
+    r = (0.0f < r_above) ? above : r;
+    // outside the range (tiny, zero, negative, infinite, NaN): rare, so one wave-wide test guards the general routine
+    const bool general = !(x >= 0x1p-96f && x <= FLT_MAX);
+    if (__ballot(general) != 0ull) {
+        float y = x;
+        asm volatile("" : "+v"(y));                         // keeps the general routine inside the rare branch (it would otherwise be
+        if (general) r = sqrtf(y);                          // computed speculatively for every call and merged with a select)
+    }
+    return r;
+}
+
 // glm::normalize = v * (1 / sqrt(dot(v, v))) (func_geometric.inl:82-90, func_exponential.inl:134-139)
-__device__ __forceinline__ F3 normalize3(F3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+__device__ __forceinline__ F3 normalize3(F3 v) { return v * (1.0f / sqrt_rn(dot3(v, v))); }
 // glm::reflect = I - N * dot(N, I) * 2 (func_geometric.inl:104-110)
 __device__ __forceinline__ F3 reflect3(F3 I, F3 N) { return I - (N * dot3(N, I)) * 2.0f; }
 // glm::mix = x * (1 - a) + y * a (func_common.inl:104-112)
@@ -213,8 +234,10 @@ __device__ __forceinline__ void trace_spheres_from(const RtParams& p, F3 O, F3 D
         float b = 2.0f * dot3(ro, D);
         float c = dot3(ro, ro) - cur.w;                    // cur.w = radius*radius, rounded once at upload
         float disc = b * b - four_a * c;
+        // (Branches, not selects: the rays of a wave are coherent enough that whole waves skip the square root and the division
+        // for most spheres; straight-line code measured a third slower.)
         if (disc >= 0.0f && b < 0.0f) {
-            float num = -b - sqrtf(disc);
+            float num = -b - sqrt_rn(disc);
             if (num > 0.0f && num < best_num) {
                 float t = num / dbl_a;
                 if (t > 0.0f && t < closest) { closest = t; index = (int)i; best_num = num; }
@@ -284,12 +307,16 @@ __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 inv
     }
     uint32_t node = 0;
     const uint32_t end = p.n_nodes;
+    // A long walk is a chain of dependent loads: once a ray has made RT_LONG_WALK steps its wave asks for issue priority, so
+    // that the few long rays that decide when the frame ends are not queued behind the bulk of short ones.
+    uint32_t steps = 0;
     for (;;) {
         int32_t leaf = -1;
         while (node < end) {
             const float4 n0 = nodes[2 * (size_t)node];
             const float4 n1 = nodes[2 * (size_t)node + 1];
             if (STATS) n_nodes_visited++;
+            if (++steps == RT_LONG_WALK) __builtin_amdgcn_s_setprio(3);
             float tNear;
             const bool box = slab_test(n0, n1, O, invD, tNear);
             // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
@@ -306,6 +333,7 @@ __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 inv
             const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
             rec += 3;
             if (STATS) n_tris_tested++;
+            if (++steps == RT_LONG_WALK) __builtin_amdgcn_s_setprio(3);
             const uint32_t tag = __float_as_uint(r2.y);
             float tt, u, v;
             if (tri_test(r0, r1, r2, O, D, tt, u, v) && (tt < t || (ORDERED && tt == t && rec_index < best_rec))) {
@@ -315,6 +343,7 @@ __device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 inv
             if (tag & 0x80000000u) break;
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
 }
 
@@ -396,7 +425,7 @@ __device__ __forceinline__ F3 random_unit_vector(unsigned long long& rng)
     const float TwoPi = 2.0f * 3.14159274f;
     float z = rng_float(rng) * 2.0f - 1.0f;
     float a = rng_float(rng) * TwoPi;
-    float r = sqrtf(1.0f - z * z);
+    float r = sqrt_rn(1.0f - z * z);
     float sn, cs;
     sincos_portable(a, sn, cs);
     return f3(r * cs, r * sn, z);
@@ -507,7 +536,7 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const Scen
         float k = 1.0f - (eta * eta) * (1.0f - i_dot_n * i_dot_n);
         if (!(k < 0.0f)) {
             s.O = P + ref_n * (-EPSILON);
-            s.D = normalize3((D + ref_n * i_dot_n) * eta - ref_n * sqrtf(k));
+            s.D = normalize3((D + ref_n * i_dot_n) * eta - ref_n * sqrt_rn(k));
             return last;                                    // "continue": skips emission, albedo and roulette
         }
         // total internal reflection: falls through with the direction unchanged
@@ -919,10 +948,11 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
     unsigned long long clock_start = 0, steps_max_sum = 0, steps_sum = 0; uint32_t n_iterations = 0;
-    if (STATS) clock_start = __builtin_amdgcn_s_memrealtime();
+    const bool clocked = p.wave_clock != nullptr;           // diagnostics: start / end time and trip count of every wave
+    if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
 
     bool live = false;
-    uint32_t pixel = 0, frame = 0;
+    uint32_t pixel = 0, frame = 0, path_steps = 0;
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
@@ -976,7 +1006,14 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
             }
         }
         if (__ballot(live) == 0ull) break;                  // nothing in flight and nothing left to take
-        if (STATS) n_iterations++;
+        n_iterations++;
+        // The two workgroups of a CU own equal shares, but instruction issue favours the older wave, so one of them would
+        // finish at half time and leave the other with half the waves per SIMD.  Issue priority alternates between the
+        // two halves of the grid every iteration, which keeps them abreast.
+        if (!DYNAMIC) {
+            if ((n_iterations ^ (blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- rays the tree cannot prune (a zero direction component): the wave walks the tree for them, one at a time
         bool have_mesh_hit = false;
@@ -1019,13 +1056,17 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
             int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
             const uint32_t steps_before = n_nodes + n_tris;
             const bool ended = path_step<MODE, STATS, ORDERED, LDS_SCENE>(s, p, lds, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris);
-            if (STATS) lane_steps = n_nodes + n_tris - steps_before;
+            if (STATS) { lane_steps = n_nodes + n_tris - steps_before; path_steps += lane_steps; }
             if (ended) {
                 if (id_out && p.bounces == 0) *id_out = -1;
                 acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
                 frame++;
                 if (frame < p.n_frames) path_begin(s, p, pixel, p.frame_first + frame);
-                else { p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f); live = false; }
+                else {
+                    // the unused fourth component carries, from the counting kernels, the node + triangle steps of the pixel's last path
+                    p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, STATS ? (float)path_steps : 0.0f); live = false;
+                }
+                path_steps = 0;
             }
         }
         if (STATS) {                                        // how unevenly the lanes of this iteration were loaded
@@ -1038,7 +1079,7 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
         }
     }
 
-    if (STATS && p.wave_clock && lane == 0) {
+    if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
         wc[3] = steps_max_sum; wc[4] = steps_sum;

@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 traffic_path = os.path.join(root, "profiles", "traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
-for cfg in (1, 2, 3):
+for cfg in (1, 2, 3, 4, 5):
     d = os.path.join(root, "gpurun_out", "prof_cfg%d" % cfg)
     summ = os.path.join(root, "gpurun_out", "prof_cfg%d_summary.json" % cfg)
     if not os.path.exists(summ):
@@ -20,7 +20,8 @@ for cfg in (1, 2, 3):
         shutil.copy(b, os.path.join(root, "profiles", "%s_cfg%d_bench.json" % (tag, cfg)))
     s = json.load(open(summ))
     for k, cs in s["counters"].items():
-        if "rt_trace_kernel" in k and "false" in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false" in k or "rt_trace_kernel<2, false" in k
+        if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             traffic["config%d" % cfg] = {
                 "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
                 "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0,

@@ -16,7 +16,8 @@ st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
 r.OnResize(w, h); r.upload(scene, cam)
 for f in range(1, 4):
     r.render_only(f)
-r.set_stats(True); r.reset_counters()
+flags = int(sys.argv[2]) if len(sys.argv) > 2 else 3       # 3 = counting kernel + wave clocks, 2 = the timed kernel + wave clocks
+r.set_stats(flags); r.reset_counters()
 r.render_only(4); r.sync()
 c = r.read_counters()
 wc = r.read_wave_clock().astype(np.float64)
@@ -44,3 +45,15 @@ if wc.shape[1] >= 5 and wc[:, 3].sum() > 0:
     print("  busiest-lane steps per iteration:", q(mx / np.maximum(it, 1)))
     print("  the 12 last waves: busiest-lane steps/iteration, balance:", [(int(mx[i] / max(it[i], 1)), round(sm[i] / (64 * max(mx[i], 1)), 2)) for i in order[:12]])
     print("  us per busiest-lane step (wave duration / sum of busiest-lane steps):", q(dur / np.maximum(mx, 1)))
+if cfg["mesh"]:
+    import torch
+    from raytracer_amd import dist as rtd
+    steps = rtd.accum_tensor(r)[..., 3].cpu().numpy()
+    print("  per-pixel path steps (nodes + triangles over all bounces):", q(steps.ravel()), " mean %.1f" % steps.mean())
+    ys, xs = np.unravel_index(np.argsort(-steps.ravel())[:10], steps.shape)
+    print("  heaviest pixels (x, y, steps):", [(int(x), int(y), int(steps[y, x])) for x, y in zip(xs, ys)])
+    rows = steps.sum(axis=1); cols = steps.sum(axis=0)
+    print("  share of all steps in the heaviest 1%% of pixels: %.3f; in rows %d..%d: %.3f" % (
+        np.sort(steps.ravel())[-steps.size // 100:].sum() / steps.sum(), 0, h // 4, rows[: h // 4].sum() / steps.sum()))
+    hist = np.histogram(steps.ravel(), bins=[0, 1, 2, 8, 32, 128, 512, 2048, 8192, 1 << 20])[0]
+    print("  histogram of path steps [0,1,2,8,32,128,512,2048,8192+]:", hist.tolist())
