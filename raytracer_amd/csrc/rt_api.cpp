@@ -22,6 +22,7 @@ extern "C" unsigned rt_trace_block(int mode);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
+extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 
@@ -85,6 +86,9 @@ struct rt_ctx {
     DevBuf<uint32_t> d_column_count, d_column_pixels, d_column_flags, d_column_block, d_column_queue_count;
     DevBuf<float4> d_column_dirs, d_column_boxes;      // boxes: 16-slot, 64-slot, 256-slot arrays back to back
     DevBuf<uint2> d_column_queue;
+    DevBuf<uint32_t> d_park_count, d_park_flags;         // bounce rays the tree cannot prune, handed to whole-chip kernels
+    DevBuf<float4> d_park_paths;
+    DevBuf<unsigned long long> d_park_best;
     DevBuf<unsigned long long> d_column_best;
     DevBuf<unsigned char> d_reached;
     bool columns_dirty = true;
@@ -93,6 +97,7 @@ struct rt_ctx {
 
     int n_cus = 0;
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
+    uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
     rt_kernel_time ktime{0, 0.0, 0.0, 0.0};
@@ -160,6 +165,8 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.column_box256 = p.column_box64 + (rt_ctx::kColumnCap + 63u) / 64u;
     p.column_queue = c->d_column_queue.ptr; p.column_queue_count = c->d_column_queue_count.ptr;
     p.column_queue_cap = rt_ctx::kColumnQueueCap;
+    p.park_count = c->d_park_count.ptr; p.park_flags = c->d_park_flags.ptr; p.park_paths = c->d_park_paths.ptr; p.park_best = c->d_park_best.ptr;
+    p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
 }
 
 // Every material index a kernel can read must be in range: the kernels do not check.
@@ -227,6 +234,9 @@ rt_ctx* rt_create(int device_id)
         hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess ||
         c->d_wave_clock.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * RT_WAVE_CLOCK_WORDS) != hipSuccess ||
         hipMemset(c->d_wave_clock.ptr, 0, c->d_wave_clock.count * sizeof(unsigned long long)) != hipSuccess ||
+        c->d_park_count.resize(1) != hipSuccess || hipMemset(c->d_park_count.ptr, 0, 4) != hipSuccess ||
+        c->d_park_flags.resize(RT_PARK_SLOTS) != hipSuccess || hipMemset(c->d_park_flags.ptr, 0, 4 * RT_PARK_SLOTS) != hipSuccess ||
+        c->d_park_paths.resize(RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
         c->d_column_stats.resize(2) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 16) != hipSuccess ||
@@ -240,6 +250,7 @@ rt_ctx* rt_create(int device_id)
         rt_destroy(c); return nullptr;
     }
     c->n_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) c->park_min_nodes = (uint32_t)v; }
     return c;
 }
 
@@ -251,6 +262,7 @@ void rt_destroy(rt_ctx* c)
     c->d_spheres.release(); c->d_materials.release(); c->d_nodes.release(); c->d_leafrecs.release();
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release(); c->d_wave_clock.release(); c->d_column_stats.release(); c->d_work_heads.release();
+    c->d_park_count.release(); c->d_park_flags.release(); c->d_park_paths.release(); c->d_park_best.release();
     c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
     c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
@@ -634,6 +646,13 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
+    if (mode != RT_SCENE_SPHERES && c->n_nodes >= c->park_min_nodes) {
+        // the paths the launch parked (bounce rays with direction.x == 0, rare): their hits by whole-chip kernels, then the rest of
+        // those paths by one workgroup of the trace kernel; all of it returns at once when nothing was parked
+        HIP_TRY(c, rt_launch_parked_rays(&p, c->stats ? 1 : 0, c->stream));
+        RtParams q = p; q.resume = 1;
+        HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, 1, c->stream));
+    }
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
     HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));

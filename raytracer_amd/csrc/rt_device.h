@@ -11,6 +11,9 @@
 
 #define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile
 #define RT_SPHERE_BLOCK 1024       // threads per workgroup of the sphere-scene trace kernel (16 waves sharing one unit counter in LDS)
+#define RT_PARK_SLOTS 2            // bounce rays the tree cannot prune that one frame can hand to whole-chip kernels
+#define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
+#define RT_PARK_WORDS 6            // float4 per parked path
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
 #define RT_WAVE_CLOCK_WORDS 5
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
@@ -88,5 +91,15 @@ struct RtParams {
     unsigned long long* column_best;         // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
     uint32_t* column_flags;                  // bit 0: the pre-pass result may not be used (a decision depended on t, or the queue overflowed)
     unsigned char* reached;                  // per node: visited by column rays (pre-pass scratch)
+    // Bounce rays with direction.x == 0 in a large tree ("parked" paths): the trace kernel stores the path and frees the lane,
+    // whole-chip kernels find the hit (same reach + test as for the column rays, one ray at a time), a one-workgroup launch of
+    // the trace kernel (resume != 0) continues the paths.
+    uint32_t* park_count;                    // paths parked by this frame's trace launch (may exceed RT_PARK_SLOTS: the excess was not parked)
+    float4*   park_paths;                    // RT_PARK_WORDS float4 per slot: origin, direction, contribution, colour, {rng lo, rng hi, bounce, pixel}, {accumulated rgb, frame}
+    unsigned long long* park_best;           // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
+    uint32_t* park_flags;                    // per slot, bit 0: the whole-chip result may not be used (a decision depended on t)
+    uint32_t  park_min_nodes;                // park only in trees with at least this many nodes
+    int32_t   ray_slot;                      // which ray the reach / test kernels serve: -1 = the column rays, else a parked slot
+    uint32_t  resume;                        // trace kernel: continue the parked paths instead of drawing units
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

@@ -769,17 +769,34 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v, uint32_t lane
     return v;
 }
 
+// The ray the reach / test kernels work for (p.ray_slot): the column rays' representative (slot 0 of the family; `count` =
+// size of the family), or one parked bounce ray (`count` = 1).  False when there is nothing to do.
+__device__ __forceinline__ bool reach_ray(const RtParams& p, F3& O, F3& D, uint32_t& count)
+{
+    if (p.ray_slot < 0) {
+        count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+        if (count == 0u) return false;
+        const float4 d4 = p.column_dirs[0];
+        O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]); D = f3(d4.x, d4.y, d4.z);
+        return true;
+    }
+    if ((uint32_t)p.ray_slot >= *p.park_count) return false;
+    const float4 o4 = p.park_paths[RT_PARK_WORDS * p.ray_slot], d4 = p.park_paths[RT_PARK_WORDS * p.ray_slot + 1];
+    O = f3(o4.x, o4.y, o4.z); D = f3(d4.x, d4.y, d4.z); count = 1u;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
 {
     __shared__ uint32_t wave_max[4];
-    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
-    if (count == 0u) return;
+    F3 O, D; uint32_t count;
+    if (!reach_ray(p, O, D, count)) return;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (gid < count) p.column_best[gid] = ~0ull;                    // fresh results for this frame (grid covers column_cap)
-    if (gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }
-    const float4 d4 = p.column_dirs[0];
-    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    const F3 invD = f3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
+    if (p.ray_slot < 0) {
+        if (gid < count) p.column_best[gid] = ~0ull;                // fresh results for this frame (grid covers column_cap)
+        if (gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }
+    } else if (gid == 0u) { p.park_best[p.ray_slot] = ~0ull; p.park_flags[p.ray_slot] = 0u; }
+    const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     bool box; float tNear;
     uint32_t m = column_kill_end(p, gid, O, invD, box, tNear);
     m = wave_inclusive_max(m, threadIdx.x & 63u);
@@ -796,7 +813,8 @@ __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
 __global__ __launch_bounds__(1024) void rt_column_reach_scan_kernel(RtParams p, uint32_t n_blocks)
 {
     __shared__ uint32_t part[1024];
-    if ((*p.column_count < p.column_cap ? *p.column_count : p.column_cap) == 0u) return;
+    F3 O, D; uint32_t count;
+    if (!reach_ray(p, O, D, count)) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_blocks + 1023u) / 1024u;
     const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
@@ -817,12 +835,10 @@ __global__ __launch_bounds__(1024) void rt_column_reach_scan_kernel(RtParams p, 
 __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, int stats)
 {
     __shared__ uint32_t wave_max[4];
-    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
-    if (count == 0u) return;
+    F3 O, D; uint32_t count;
+    if (!reach_ray(p, O, D, count)) return;
     const uint32_t j = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const float4 d4 = p.column_dirs[0];
-    const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
-    const F3 invD = f3(1.0f / d4.x, 1.0f / d4.y, 1.0f / d4.z);
+    const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     bool box; float tNear;
     const uint32_t own = column_kill_end(p, j, O, invD, box, tNear);
     const uint32_t incl = wave_inclusive_max(own, lane);
@@ -836,10 +852,32 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     const bool visited = j < p.n_nodes && j >= limit;
     if (j < p.n_nodes) p.reached[j] = (visited && box) ? 1 : 0;
     // a visited box with a real t_near could be pruned by the closest t so far: then the visited set is not fixed
-    if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.column_flags, 1u);
+    if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.ray_slot < 0 ? p.column_flags : p.park_flags + p.ray_slot, 1u);
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(__ballot(visited));
-        if (lane == 0u && n) atomicAdd(&p.column_stats[0], (unsigned long long)n * count);  // every column ray visits these nodes
+        if (lane == 0u && n) atomicAdd(&p.column_stats[0], (unsigned long long)n * count);  // every ray of the family visits these nodes
+    }
+}
+
+// A parked ray against every record of the leaves it visits: the real triangle test, min (t, record index).
+__global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p, int stats)
+{
+    F3 O, D; uint32_t count;
+    if (!reach_ray(p, O, D, count) || (p.park_flags[p.ray_slot] & 1u)) return;
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    bool use = false;
+    float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
+    if (stats) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(use));
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n);
+    }
+    if (!use) return;
+    const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
+    float tt, u, v;
+    if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
+        atomicMin(&p.park_best[p.ray_slot], key);
     }
 }
 
@@ -847,7 +885,7 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
 __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int stats)
 {
     const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
-    if (count == 0u) return;
+    if (count == 0u || (*p.column_flags & 1u)) return;
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     bool use = false;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
@@ -948,7 +986,7 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
     unsigned long long clock_start = 0, steps_max_sum = 0, steps_sum = 0; uint32_t n_iterations = 0;
-    const bool clocked = p.wave_clock != nullptr;           // diagnostics: start / end time and trip count of every wave
+    const bool clocked = p.wave_clock != nullptr && !p.resume;           // diagnostics: start / end time and trip count of every wave
     if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
 
     bool live = false;
@@ -956,6 +994,23 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
+    bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
+    if (DYNAMIC && p.resume) {
+        heads_empty = RT_WORK_HEADS;                        // no units: only the parked paths are finished
+        const uint32_t n_parked = *p.park_count < RT_PARK_SLOTS ? *p.park_count : RT_PARK_SLOTS;
+        if (wave != 0u || n_parked == 0u) return;
+        if (lane < n_parked) {
+            const float4* q = p.park_paths + RT_PARK_WORDS * lane;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            s.O = f3(q0.x, q0.y, q0.z); s.column_slot = __float_as_uint(q0.w);
+            s.D = f3(q1.x, q1.y, q1.z); s.bounce = __float_as_uint(q1.w);
+            s.contribution = f3(q2.x, q2.y, q2.z); pixel = __float_as_uint(q2.w);
+            s.finalColor = f3(q3.x, q3.y, q3.z); frame = __float_as_uint(q3.w);
+            acc = f3(q4.x, q4.y, q4.z);
+            s.rng = ((unsigned long long)__float_as_uint(q5.y) << 32) | (unsigned long long)__float_as_uint(q5.x);
+            live = true; parked_hit_ready = true;
+        }
+    }
 
     for (;;) {
         // ---- give idle lanes pixels while there are units left
@@ -1032,6 +1087,37 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
                 }
                 have_mesh_hit = true;
                 unprunable = false;
+            }
+            // a parked path comes back with its hit (unless a decision of its walk depended on t: then it is walked here)
+            if (DYNAMIC && parked_hit_ready) {
+                parked_hit_ready = false;
+                if (unprunable && (p.park_flags[lane] & 1u) == 0u) {
+                    const unsigned long long key = p.park_best[lane];
+                    if (key != ~0ull) {
+                        const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        float tt, u, v;
+                        tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
+                        mesh_hit.t = tt; mesh_hit.u = u; mesh_hit.v = v; mesh_hit.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
+                    }
+                    have_mesh_hit = true;
+                    unprunable = false;
+                }
+            }
+            // in a large tree such a walk takes one wave a large part of a second while the chip idles: park the path (the
+            // lane takes other pixels), let whole-chip kernels find its hit after this launch, finish it in a resume launch
+            if (DYNAMIC && unprunable && !p.resume && p.n_nodes >= p.park_min_nodes) {
+                const uint32_t slot = atomicAdd(p.park_count, 1u);
+                if (slot < RT_PARK_SLOTS) {
+                    float4* q = p.park_paths + RT_PARK_WORDS * slot;
+                    q[0] = make_float4(s.O.x, s.O.y, s.O.z, __uint_as_float(s.column_slot));
+                    q[1] = make_float4(s.D.x, s.D.y, s.D.z, __uint_as_float(s.bounce));
+                    q[2] = make_float4(s.contribution.x, s.contribution.y, s.contribution.z, __uint_as_float(pixel));
+                    q[3] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, __uint_as_float(frame));
+                    q[4] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+                    q[5] = make_float4(__uint_as_float((uint32_t)s.rng), __uint_as_float((uint32_t)(s.rng >> 32)), 0.0f, 0.0f);
+                    live = false; unprunable = false;
+                }
             }
             unsigned long long todo = __ballot(unprunable);
             while (todo != 0ull) {
@@ -1124,6 +1210,7 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t fr
     const uint32_t y = band * RT_TILE + (wave >> 1) * 8u + (lane >> 3);
     // the trace kernel that produced this frame has drained the unit queue: zero its heads for the next trace launch
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.park_count = 0u;
     if (x < p.width && y < p.height) {
         const uint32_t pixel = y * p.width + x;
         float4 a = p.accum[pixel];
@@ -1220,16 +1307,35 @@ extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s)
     return hipGetLastError();
 }
 
+static void launch_reach(const RtParams& p, int stats, hipStream_t s)
+{
+    const unsigned node_blocks = (p.n_nodes + 255u) / 256u;
+    const unsigned cap_blocks = (p.column_cap + 255u) / 256u;                  // the first kernel also clears the column rays' results
+    const unsigned first_grid = (p.ray_slot < 0 && cap_blocks > node_blocks) ? cap_blocks : node_blocks;
+    hipLaunchKernelGGL(rt_column_reach_max_kernel, dim3(first_grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(rt_column_reach_scan_kernel, dim3(1), dim3(1024), 0, s, p, node_blocks);
+    hipLaunchKernelGGL(rt_column_reach_mark_kernel, dim3(node_blocks), dim3(256), 0, s, p, stats);
+}
+
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s)
 {
-    unsigned node_blocks = (p->n_nodes + 255u) / 256u;
-    const unsigned cap_blocks = (p->column_cap + 255u) / 256u;                 // the first kernel also clears the per-ray results
-    const unsigned first_grid = node_blocks > cap_blocks ? node_blocks : cap_blocks;
-    hipLaunchKernelGGL(rt_column_reach_max_kernel, dim3(first_grid), dim3(256), 0, s, *p);
-    hipLaunchKernelGGL(rt_column_reach_scan_kernel, dim3(1), dim3(1024), 0, s, *p, node_blocks);
-    hipLaunchKernelGGL(rt_column_reach_mark_kernel, dim3(node_blocks), dim3(256), 0, s, *p, stats);
-    hipLaunchKernelGGL(rt_column_filter_kernel, dim3((p->n_refs + 255u) / 256u), dim3(256), 0, s, *p, stats);
-    hipLaunchKernelGGL(rt_column_exact_kernel, dim3(2048), dim3(256), 0, s, *p);
+    RtParams q = *p; q.ray_slot = -1;
+    launch_reach(q, stats, s);
+    hipLaunchKernelGGL(rt_column_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+    hipLaunchKernelGGL(rt_column_exact_kernel, dim3(2048), dim3(256), 0, s, q);
+    return hipGetLastError();
+}
+
+// After a trace launch over a large tree: the hits of the paths it parked, slot by slot (each kernel returns at once when the
+// slot is empty).  The resume launch of the trace kernel follows.
+extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s)
+{
+    RtParams q = *p;
+    for (int slot = 0; slot < RT_PARK_SLOTS; ++slot) {
+        q.ray_slot = slot;
+        launch_reach(q, stats, s);
+        hipLaunchKernelGGL(rt_park_test_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+    }
     return hipGetLastError();
 }
 

@@ -529,6 +529,22 @@ def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
 
 
 # ---- rays with exactly-zero direction components (NaN slab tests) -----------------------------------------------------------
+@pytest.fixture
+def parking_renderer(rt, monkeypatch):
+    """A context that parks tree-unprunable bounce rays even in a tiny tree (normally only from 2^18 nodes up), so the
+    whole-chip reach + test kernels and the resume launch run on the small meshes the oracle can check."""
+    monkeypatch.setenv("RT_PARK_MIN_NODES", "1")
+    return rt.Renderer(0)
+
+
+@pytest.mark.parametrize("order", ORDERS)
+@pytest.mark.parametrize("mode", [0, 2])
+def test_zero_direction_rays_parked_and_resumed(rt, orc, parking_renderer, mode, order):
+    """Same planted zero components as the test below, through the parking path: more such rays than parking slots, so some
+    are parked and resumed and the rest are walked in the kernel, in one frame."""
+    test_zero_direction_components_all_patterns(rt, orc, parking_renderer, mode, order)
+
+
 @pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("mode", [0, 2])
 def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
