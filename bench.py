@@ -225,6 +225,16 @@ def main():
                               "tris_per_ray": (c3.tris_tested - c3.prepass_tris) / max(c3.rays, 1)}
                 st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
             r.set_stats(False)
+            # grazing ties: primary ids that differ between the reference walk order and front to back (one frame each, untimed)
+            order_ties = None
+            if order_used != "reference" and world == 1:
+                ids = {}
+                for o in (1, 2):
+                    st.TraversalOrder = o; r.push_settings(); r.record_ids(True)
+                    r.render_only(1); ids[o] = r.read_primary_ids()
+                r.record_ids(False)
+                st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
+                order_ties = {"primary_ids_differing_from_reference_order": int((ids[1] != ids[2]).sum()), "pixels": int(px)}
             per_launch = lambda v: v / max(len(frames), 1)
             # what the trace kernel itself walked: the counters minus the part that stands for the column rays (primary rays with
             # direction.x == +0), which the pre-pass resolves without walking the tree ray by ray
@@ -241,6 +251,7 @@ def main():
                     "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
                     "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
                     "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
+                    "grazing_ties": order_ties,
                     "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
                             "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
                             "that was timed; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "

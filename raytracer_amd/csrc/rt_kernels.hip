@@ -859,25 +859,27 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     }
 }
 
-// A parked ray against every record of the leaves it visits: the real triangle test, min (t, record index).
+// A parked ray against every record of the leaves it visits: the real triangle test, min (t, record index).  A fixed grid
+// strides over the records, so that the launch costs next to nothing when the slot is empty (the usual case).
 __global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p, int stats)
 {
     F3 O, D; uint32_t count;
     if (!reach_ray(p, O, D, count) || (p.park_flags[p.ray_slot] & 1u)) return;
-    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-    bool use = false;
-    float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
-    if (stats) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(use));
-        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n);
-    }
-    if (!use) return;
-    const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
-    float tt, u, v;
-    if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
-        atomicMin(&p.park_best[p.ray_slot], key);
+    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r - threadIdx.x < p.n_refs; r += gridDim.x * 256u) {
+        bool use = false;
+        float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
+        if (stats) {
+            const uint32_t n = (uint32_t)__popcll(__ballot(use));
+            if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n);
+        }
+        if (!use) continue;
+        const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
+        float tt, u, v;
+        if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
+            atomicMin(&p.park_best[p.ray_slot], key);
+        }
     }
 }
 
@@ -1334,7 +1336,8 @@ extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStr
     for (int slot = 0; slot < RT_PARK_SLOTS; ++slot) {
         q.ray_slot = slot;
         launch_reach(q, stats, s);
-        hipLaunchKernelGGL(rt_park_test_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+        const unsigned rec_blocks = (q.n_refs + 255u) / 256u;
+        hipLaunchKernelGGL(rt_park_test_kernel, dim3(rec_blocks < 4096u ? rec_blocks : 4096u), dim3(256), 0, s, q, stats);
     }
     return hipGetLastError();
 }

@@ -447,6 +447,55 @@ def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
     assert np.array_equal(bits(full[REF_ORDER]), bits(full[F2B_ORDER]))      # every pixel, not only the oracle's rows
 
 
+def test_configs4_and_5_ten_million_triangles_4k(rt, orc, renderer):
+    """BASELINE configs[3] and [4] at full size: the 9,999,392-triangle mesh (KD tree of ~16 M nodes, ~7 GB in HBM) at
+    3840x2160, mesh alone (8 bounces) and with the default spheres.  Against the oracle: every 240th row (the oracle needs
+    ~40 s per full frame on 16 cores), ids and accumulation bit-exact in both walk orders, which also covers the column of
+    direction.x == 0.  Over all pixels the two orders are compared with each other (see below)."""
+    import bench
+    cfg = bench.CONFIGS[4]
+    scene = bench.build_scene(cfg)
+    osc = orc.Scene()
+    osc.set_spheres(scene.spheres); osc.set_materials(scene.materials)
+    osc.set_mesh(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat)
+    osc.import_kd(scene.kd_tree.arrays())
+    w, h = cfg["w"], cfg["h"]
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    rows = np.arange(0, h, 240)
+    st = renderer.GetSettings()
+    renderer.download = False
+    try:
+        for mode, bounces in ((0, 8), (2, 8)):
+            st.SceneMode, st.Bounces, st.AntiAliasing, st.Accumulate, st.UseACE_Color, st.Seed = mode, bounces, False, True, True, 1337
+            acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.full(h * w, -7, np.int32)
+            osc.render_frame(orc.Settings(1, mode, 1, 0, bounces), cam.GetPosition(), dirs, w, h, 1, acc, img, primary_ids=ids,
+                             nthreads=16, row_step=240)
+            full = {}
+            for order in (REF_ORDER, F2B_ORDER):
+                st.TraversalOrder = order
+                renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
+                renderer.Render(scene, cam)
+                full[order] = (renderer.read_primary_ids().copy(), renderer.read_accum().copy())
+                assert np.array_equal(full[order][0][rows], ids.reshape(h, w)[rows]), "mode %d order %d: primary ids" % (mode, order)
+                assert np.array_equal(bits(full[order][1][rows]), bits(acc.reshape(h, w, 3)[rows])), "mode %d order %d: accumulation" % (mode, order)
+            # all 8.3 M pixels: the two orders may only differ at grazing ties (two triangles hit within rounding distance of
+            # each other exactly on a leaf boundary); such pixels are counted, must be a handful, and on each of them the
+            # reference order must be what the oracle says
+            differ = np.flatnonzero(full[REF_ORDER][0].ravel() != full[F2B_ORDER][0].ravel())
+            assert len(differ) <= 4, "%d primary ids differ between the walk orders" % len(differ)
+            if len(differ) and mode == 0:
+                o_ids, *_ = osc.trace_primary(0, cam.GetPosition(), dirs.reshape(-1, 3)[differ])
+                assert np.array_equal(full[REF_ORDER][0].ravel()[differ], o_ids)
+            acc_differ = (bits(full[REF_ORDER][1]) != bits(full[F2B_ORDER][1])).any(axis=-1).sum()
+            assert acc_differ <= 16, "%d pixels of accumulated radiance differ between the walk orders" % acc_differ
+            print("mode %d: %d primary ids, %d radiance pixels differ between walk orders (of %d)" % (mode, len(differ), acc_differ, w * h))
+            hit = full[F2B_ORDER][0] >= 0
+            assert hit.mean() > 0.15 and (full[F2B_ORDER][0] >= 0x40000000).sum() > 200000   # the mesh is seen
+    finally:
+        st.TraversalOrder = 0; renderer.download = True
+
+
 # ---- plumbing for the multi-GPU path, on one GPU ------------------------------------------------------------------------------
 def test_accum_tensor_aliases_the_device_buffer(rt, orc, renderer):
     """raytracer_amd.dist hands torch a zero-copy view of the accumulation buffer (what the RCCL sum runs on)."""
