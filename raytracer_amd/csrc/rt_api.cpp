@@ -643,6 +643,9 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
         HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
         HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
     } else p.column_best = nullptr;
+    // sphere frames resolve inside the trace kernel; the 3x3 filter needs the neighbours' sums and keeps the separate pass
+    const bool fused = mode == RT_SCENE_SPHERES && !c->settings.anti_aliasing;
+    p.fuse_resolve = fused ? 1u : 0u;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
@@ -655,7 +658,7 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     }
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
-    HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));
+    if (!fused) HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));
     if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index + n - 1, gx, gy, c->stream));
     return RT_OK;
 }

@@ -60,6 +60,7 @@ struct RtParams {
     uint32_t tile_rows, n_units;           // 8-row tile rows / RT_UNIT-pixel work units in the bands this context renders
     uint32_t* work_heads;                  // RT_WORK_HEADS ticket counters (RT_HEAD_STRIDE words apart), zero before every trace launch
     int32_t  use_ace;
+    uint32_t fuse_resolve;                  // sphere trace kernel: each workgroup also resolves its share of the image
     const float4* spheres;
     const uint32_t* sphere_mat;
     const float4* materials;

@@ -1167,6 +1167,22 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
         }
     }
 
+    // Sphere frames without the 3x3 filter: the workgroup resolves its own share of the image as soon as its last wave is
+    // done (Renderer.cpp:68-79).  The sums were just written by this CU (L2-resident), every lane is busy, and the work fills
+    // the time in which other workgroups still trace -- instead of a separate pass over the whole frame after the launch.
+    if (!DYNAMIC && p.fuse_resolve) {
+        __syncthreads();
+        const uint32_t share = p.n_units > blockIdx.x ? (p.n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
+        const float div = (float)(p.frame_first + p.n_frames - 1u);
+        for (uint32_t i = threadIdx.x; i < share * RT_UNIT; i += blockDim.x) {
+            uint32_t px;
+            if (unit_pixel(p, blockIdx.x + gridDim.x * (i / RT_UNIT), i % RT_UNIT, px)) {
+                const float4 a = p.accum[px];
+                p.image[px] = resolve_px(f3(a.x, a.y, a.z), div, p.use_ace);
+            }
+        }
+    }
+
     if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
