@@ -97,7 +97,6 @@ public:
             m_Image = std::make_shared<ImageT>(width, height, kFormat);
         }
         check(rt_resize(m_ctx, width, height), "rt_resize");
-        m_ImageData.assign((size_t)4 * width * height, 0.0f);
         ResetFrameIndex();
     }
 
@@ -134,8 +133,9 @@ public:
 
         check(rt_render(m_ctx, m_frameindex), "rt_render");
         if (m_settings.Accumulate) m_frameindex++; else m_frameindex = 1;      // Renderer.cpp:128-131
-        check(rt_read_image(m_ctx, m_ImageData.data()), "rt_read_image");
-        m_Image->SetData(m_ImageData.data());                                   // Renderer.cpp:134
+        const float* frame = rt_map_image(m_ctx);                               // page-locked staging owned by the library
+        if (!frame) check(RT_E_HIP, "rt_map_image");
+        m_Image->SetData(frame);                                                // Renderer.cpp:134
     }
 
     std::shared_ptr<ImageT> GetImage() { return m_Image; }
@@ -174,7 +174,6 @@ private:
     rt_ctx* m_ctx;
     Settings m_settings;
     std::shared_ptr<ImageT> m_Image;
-    std::vector<float> m_ImageData;
     std::vector<rt_sphere> m_spheres;
     std::vector<rt_material> m_materials;
     const void* m_tree_key = nullptr;

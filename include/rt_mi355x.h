@@ -154,6 +154,10 @@ int rt_sync(rt_ctx*);
 /* m_ImageData -> Walnut::Image::SetData (Renderer.cpp:134, Walnut/Image.h:23): width*height*4 floats RGBA32F,
    row 0 first.  Synchronises. */
 int rt_read_image(rt_ctx*, float* out_rgba32f);
+/* The same frame without the caller's buffer: copied into page-locked host memory the library owns (twice the PCIe rate
+   of a copy into pageable memory, and no second host copy) and returned by address -- hand it straight to
+   Walnut::Image::SetData.  Valid until the next rt_map_image / rt_resize / rt_destroy.  NULL on failure.  Synchronises. */
+const float* rt_map_image(rt_ctx*);
 /* m_AccumulationBuffer (Renderer.h:157): width*height*3 floats. */
 int rt_read_accum(rt_ctx*, float* out_rgb);
 /* closestSphereIndex / closestTriangleIndex of the primary ray (Renderer.cpp:233-237): -1 miss, sphere index,

@@ -20,7 +20,7 @@ ID_TRI_BIT = 0x40000000
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_settings", "rt_set_spheres",
     "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_traversal_in_use", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
-    "rt_render_frames", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_read_accum", "rt_set_record_ids",
+    "rt_render_frames", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_map_image", "rt_read_accum", "rt_set_record_ids",
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters", "rt_read_wave_clock",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_device_accum", "rt_device_image",
     "rt_host_camera_default_forward", "rt_host_camera_matrices", "rt_host_kd_build", "rt_host_kd_flat", "rt_host_kd_free",
@@ -87,7 +87,7 @@ def lib():
         "rt_set_kdtree": ([vp, vp], C.c_int), "rt_traversal_in_use": ([vp], C.c_int), "rt_set_camera": ([vp, vp, vp, vp], C.c_int),
         "rt_set_ray_dirs": ([vp, vp, sz], C.c_int), "rt_set_bands": ([vp, u32, u32], C.c_int),
         "rt_render": ([vp, u32], C.c_int), "rt_render_frames": ([vp, u32, u32], C.c_int),
-        "rt_resolve": ([vp, u32], C.c_int), "rt_reset_accum": ([vp], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int),
+        "rt_resolve": ([vp, u32], C.c_int), "rt_reset_accum": ([vp], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int), "rt_map_image": ([vp], vp),
         "rt_read_accum": ([vp, vp], C.c_int), "rt_set_record_ids": ([vp, C.c_int], C.c_int),
         "rt_read_primary_ids": ([vp, vp], C.c_int), "rt_read_ray_dirs": ([vp, vp], C.c_int),
         "rt_set_stats": ([vp, C.c_int], C.c_int), "rt_read_counters": ([vp, vp], C.c_int),

@@ -77,6 +77,8 @@ struct rt_ctx {
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
     uint32_t last_grid_waves = 0;
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
+    float* h_image = nullptr;            // page-locked staging for rt_map_image
+    size_t h_image_bytes = 0;
     bool use_host_dirs = false;          // d_dirs holds directions the host supplied (rt_set_ray_dirs)
     bool dirs_dirty = true;              // d_dirs must be regenerated from the camera before the next trace
 
@@ -270,6 +272,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
+    if (c->h_image) (void)hipHostFree(c->h_image);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -702,6 +705,24 @@ int rt_read_image(rt_ctx* c, float* out)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_image.ptr, (size_t)c->width * c->height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     return rt_sync(c);
+}
+
+const float* rt_map_image(rt_ctx* c)
+{
+    if (!c) return nullptr;
+    if (!c->width) { fail(c, RT_E_STATE, "no frame"); return nullptr; }
+    DeviceGuard g(c->device);
+    const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
+    if (c->h_image_bytes != bytes) {
+        if (c->h_image) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_image); c->h_image = nullptr; c->h_image_bytes = 0; }
+        hipError_t e = hipHostMalloc((void**)&c->h_image, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { fail(c, RT_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); c->h_image = nullptr; return nullptr; }
+        c->h_image_bytes = bytes;
+    }
+    hipError_t e = hipMemcpyAsync(c->h_image, c->d_image.ptr, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) { fail(c, RT_E_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e)); return nullptr; }
+    if (rt_sync(c) != RT_OK) return nullptr;
+    return c->h_image;
 }
 
 int rt_read_accum(rt_ctx* c, float* out_rgb)

@@ -163,7 +163,7 @@ class Image:
     def GetHeight(self): return self._h
 
     def SetData(self, data):
-        self.data = data
+        self.data = np.array(data, dtype=np.float32, copy=True)      # Walnut::Image::SetData copies out of the caller's buffer
 
 
 class Renderer:
@@ -209,7 +209,7 @@ class Renderer:
         else:
             self.m_frameindex = 1
         if self.download:
-            self.m_Image.SetData(self.read_image())
+            self.m_Image.SetData(self.map_image())           # Image.SetData copies, as Walnut::Image::SetData does
 
     # ---- pieces ----------------------------------------------------------------------------------
     def upload(self, scene, camera):
@@ -277,6 +277,15 @@ class Renderer:
         out = np.empty((h, w, 4), np.float32)
         check(self._h, self._L.rt_read_image(self._h, ptr(out)), "rt_read_image")
         return out
+
+    def map_image(self):
+        """The frame in the library's page-locked staging buffer, as an (h, w, 4) view (valid until the next map_image /
+        OnResize): what a display path hands to Image::SetData without another copy."""
+        w, h = self._size()
+        p = self._L.rt_map_image(self._h)
+        if not p:
+            check(self._h, -1, "rt_map_image")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h, w, 4))
 
     def read_accum(self):
         w, h = self._size()
