@@ -484,8 +484,9 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
 
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_nodes.resize(8 * 2 * (size_t)M));
-    HIP_TRY(c, c->d_leafrecs.resize(recs.empty() ? 3 : recs.size()));
+    // the walk reads RT_WALK_FETCH consecutive float4 at its cursor (three nodes or two leaf records): pad the ends
+    HIP_TRY(c, c->d_nodes.resize(8 * 2 * (size_t)M + RT_WALK_FETCH));
+    HIP_TRY(c, c->d_leafrecs.resize((recs.empty() ? 3 : recs.size()) + RT_WALK_FETCH));
 
     // Eight node arrays, one per sign pattern of a ray direction (bit a set: direction[a] < 0).  Array o is the tree in the
     // preorder that walks, at every two-child node, the child on the side a ray of that pattern comes from first.  Array 0

@@ -14,6 +14,7 @@
 #define RT_PARK_SLOTS 2            // bounce rays the tree cannot prune that one frame can hand to whole-chip kernels
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_WORDS 6            // float4 per parked path
+#define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
 #define RT_WAVE_CLOCK_WORDS 5
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own

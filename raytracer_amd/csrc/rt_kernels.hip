@@ -285,68 +285,6 @@ __device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, 
     return ok && (tt > 0.00001f);
 }
 
-// ORDERED = false: the walk of KDTreeCPU::intersect itself (node array 0 is the reference's preorder).
-// ORDERED = true : node array number (direction.x < 0) + 2 (direction.y < 0) + 4 (direction.z < 0) holds the same tree in
-// the preorder that puts, at every node, the child on the near side of this ray first; boxes, triangle tests and the
-// pruning rule are unchanged, so once a hit is known almost everything behind it is pruned.  Equal t is resolved to the
-// smaller leaf-record index, i.e. to the triangle the reference order reaches first.
-// Both forms alternate between "walk nodes until a leaf is reached" and "test that leaf's triangles", so that the lanes
-// of a wave spend their iterations in the same kind of work.
-template <bool STATS, bool ORDERED>
-__device__ __forceinline__ void trace_mesh(const RtParams& p, F3 O, F3 D, F3 invD, Hit& hit, uint32_t& n_nodes_visited,
-                                           uint32_t& n_tris_tested)
-{
-    float t = FLT_MAX;
-    int32_t tri = -1;
-    float hu = 0.0f, hv = 0.0f;
-    uint32_t best_rec = 0xFFFFFFFFu;
-    const float4* nodes = p.nodes;
-    if (ORDERED) {
-        const uint32_t octant = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
-        nodes += (size_t)octant * 2u * (size_t)p.n_nodes;
-    }
-    uint32_t node = 0;
-    const uint32_t end = p.n_nodes;
-    // A long walk is a chain of dependent loads: once a ray has made RT_LONG_WALK steps its wave asks for issue priority, so
-    // that the few long rays that decide when the frame ends are not queued behind the bulk of short ones.
-    uint32_t steps = 0;
-    for (;;) {
-        int32_t leaf = -1;
-        while (node < end) {
-            const float4 n0 = nodes[2 * (size_t)node];
-            const float4 n1 = nodes[2 * (size_t)node + 1];
-            if (STATS) n_nodes_visited++;
-            if (++steps == RT_LONG_WALK) __builtin_amdgcn_s_setprio(3);
-            float tNear;
-            const bool box = slab_test(n0, n1, O, invD, tNear);
-            // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
-            const bool descend = box && !(tNear > t);
-            const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
-            if (descend && leaf_first == RT_LEAF_INTERIOR) { node = node + 1; continue; }
-            node = __float_as_uint(n0.w);                   // skip link: first node after this subtree
-            if (descend && leaf_first >= 0) { leaf = leaf_first; break; }
-        }
-        if (leaf < 0) break;
-        uint32_t rec_index = (uint32_t)leaf;
-        const float4* rec = p.leafrecs + 3 * (size_t)leaf;
-        for (;;) {
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            rec += 3;
-            if (STATS) n_tris_tested++;
-            if (++steps == RT_LONG_WALK) __builtin_amdgcn_s_setprio(3);
-            const uint32_t tag = __float_as_uint(r2.y);
-            float tt, u, v;
-            if (tri_test(r0, r1, r2, O, D, tt, u, v) && (tt < t || (ORDERED && tt == t && rec_index < best_rec))) {
-                t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; best_rec = rec_index;
-            }
-            ++rec_index;
-            if (tag & 0x80000000u) break;
-        }
-    }
-    __builtin_amdgcn_s_setprio(0);
-    hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
-}
-
 // A ray with direction.x == 0 exactly has an infinite inverse there, and the slab test then yields NaN for every box on one
 // side of the origin (inf - inf): such a box counts as hit with t_near = NaN and "NaN > t" never prunes it.  (A zero in y or z
 // does not stick: the reference's select order drops those NaNs and the ray is pruned as usual.)  Every
@@ -470,31 +408,14 @@ __device__ __forceinline__ void stage_scene(const RtParams& p, SceneLds& lds)
     for (uint32_t i = threadIdx.x; i < 3u * p.n_materials; i += blockDim.x) lds.materials[i] = p.materials[i];
 }
 
-// One iteration of the bounce loop (Renderer.cpp:149-226).  Returns true when the path has ended (miss, roulette, or the
-// bounce budget is used up).
-template <int MODE, bool STATS, bool ORDERED, bool in_lds>
-__device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const SceneLds& lds, int32_t* primary_id, bool have_mesh_hit, Hit mesh_hit,
-                                          uint32_t& n_rays, uint32_t& n_nodes, uint32_t& n_tris)
+// What follows TraceRay in one iteration of the bounce loop (Renderer.cpp:160-226): miss, closest-hit, the next ray, emission,
+// albedo and roulette.  `first` / `last`: this was the path's first bounce / the bounce budget is used up after it.  Returns
+// true when the path has ended.
+template <int MODE, bool in_lds>
+__device__ __forceinline__ bool shade_hit(Path& s, const RtParams& p, const SceneLds& lds, int32_t* primary_id, bool first, bool last,
+                                          float tS, int iS, Hit th)
 {
-    if (s.bounce >= p.bounces) return true;                // "for (i = 0; i < Bounces; i++)" with Bounces == 0
-    const bool first = s.bounce == 0;
-    s.bounce++;
-    const bool last = s.bounce >= p.bounces;
-    n_rays++;
-
-    F3 O = s.O, D = s.D;
-    // TraceRay (Renderer.cpp:231-301)
-    float tS = FLT_MAX; int iS = -1;
-    Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
-    if (MODE == RT_MODE_SPHERES || MODE == RT_MODE_BOTH) trace_spheres(p, O, D, tS, iS);
-    if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) {
-        if (have_mesh_hit) th = mesh_hit;                   // found by the whole wave (zero direction component)
-        else {
-            F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);  // Renderer.cpp:151
-            trace_mesh<STATS, ORDERED>(p, O, D, invD, th, n_nodes, n_tris);
-        }
-    }
-
+    const F3 O = s.O, D = s.D;
     if (iS < 0 && th.id < 0) {                             // Miss(): finalColor += contribution * ambient (= 0), break
         s.finalColor = s.finalColor + s.contribution * f3(0.0f, 0.0f, 0.0f);
         if (primary_id && first) *primary_id = -1;
@@ -553,6 +474,22 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const Scen
     if (rng_float(s.rng) > pr) return true;                 // Russian roulette (Renderer.cpp:218-225)
     s.contribution = s.contribution * (1.0f / pr);
     return last;
+}
+
+// One iteration of the bounce loop (Renderer.cpp:149-226) in a scene of spheres.  Returns true when the path has ended (miss,
+// roulette, or the bounce budget is used up).
+template <bool in_lds>
+__device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const SceneLds& lds, int32_t* primary_id, uint32_t& n_rays)
+{
+    if (s.bounce >= p.bounces) return true;                // "for (i = 0; i < Bounces; i++)" with Bounces == 0
+    const bool first = s.bounce == 0;
+    s.bounce++;
+    const bool last = s.bounce >= p.bounces;
+    n_rays++;
+    float tS = FLT_MAX; int iS = -1;                        // TraceRay (Renderer.cpp:231-301)
+    trace_spheres(p, s.O, s.D, tS, iS);
+    Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
+    return shade_hit<RT_MODE_SPHERES, in_lds>(s, p, lds, primary_id, first, last, tS, iS, th);
 }
 
 // Pixel `slot` of work unit `unit`: units are the four 8x2 strips of each 8x8 tile of the 16-row bands this context
@@ -969,208 +906,83 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 //                  one per 16 idle lanes and all of a refill with one atomic, so a wave never owns pixels it cannot start at
 //                  once -- otherwise the last units trickle through a few lanes of one wave while the rest of the chip idles.
 __device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h) { return (p.n_units + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS; }
+__device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t) { return h + RT_WORK_HEADS * t; }
 
-template <int MODE, bool STATS, bool ORDERED, bool LDS_SCENE>
-__device__ __forceinline__ void trace_body(const RtParams& p)
+template <bool STATS, bool LDS_SCENE>
+__device__ __forceinline__ void sphere_body(const RtParams& p)
 {
-    constexpr bool DYNAMIC = MODE != RT_MODE_SPHERES;
     __shared__ SceneLds lds;                                // only allocated where LDS_SCENE variants use it
-    __shared__ uint32_t wg_next;                            // spheres: how many of this workgroup's units have been handed out
+    __shared__ uint32_t wg_next;                            // how many of this workgroup's units have been handed out
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (threadIdx.x == 0) wg_next = 0u;
     if (LDS_SCENE) stage_scene(p, lds);
     __syncthreads();
-    // wave-uniform.  Workgroup share: current unit and its first free pixel (RT_UNIT = used up).  Tickets: the head drawn from,
-    // heads found empty.
+    // wave-uniform: current unit of the workgroup's share and its first free pixel (RT_UNIT = used up)
     uint32_t unit = 0, slot = RT_UNIT;
     bool share_done = false;
-    uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;
-    uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
-    unsigned long long clock_start = 0, steps_max_sum = 0, steps_sum = 0; uint32_t n_iterations = 0;
-    const bool clocked = p.wave_clock != nullptr && !p.resume;           // diagnostics: start / end time and trip count of every wave
+    uint32_t n_rays = 0;
+    unsigned long long clock_start = 0; uint32_t n_iterations = 0;
+    const bool clocked = p.wave_clock != nullptr;           // diagnostics: start / end time and trip count of every wave
     if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
 
     bool live = false;
-    uint32_t pixel = 0, frame = 0, path_steps = 0;
+    uint32_t pixel = 0, frame = 0;
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
-    bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
-    if (DYNAMIC && p.resume) {
-        heads_empty = RT_WORK_HEADS;                        // no units: only the parked paths are finished
-        const uint32_t n_parked = *p.park_count < RT_PARK_SLOTS ? *p.park_count : RT_PARK_SLOTS;
-        if (wave != 0u || n_parked == 0u) return;
-        if (lane < n_parked) {
-            const float4* q = p.park_paths + RT_PARK_WORDS * lane;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-            s.O = f3(q0.x, q0.y, q0.z); s.column_slot = __float_as_uint(q0.w);
-            s.D = f3(q1.x, q1.y, q1.z); s.bounce = __float_as_uint(q1.w);
-            s.contribution = f3(q2.x, q2.y, q2.z); pixel = __float_as_uint(q2.w);
-            s.finalColor = f3(q3.x, q3.y, q3.z); frame = __float_as_uint(q3.w);
-            acc = f3(q4.x, q4.y, q4.z);
-            s.rng = ((unsigned long long)__float_as_uint(q5.y) << 32) | (unsigned long long)__float_as_uint(q5.x);
-            live = true; parked_hit_ready = true;
-        }
-    }
 
     for (;;) {
         // ---- give idle lanes pixels while there are units left
         unsigned long long need = __ballot(!live);
-        if (DYNAMIC) {
-            uint32_t want = (uint32_t)__popcll(need) / RT_UNIT;
-            while (want != 0u && heads_empty < RT_WORK_HEADS) {
-                const uint32_t count = head_count(p, head);
-                uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(p.work_heads + head * RT_HEAD_STRIDE, want);
-                t = __builtin_amdgcn_readfirstlane(t);
-                const uint32_t got = t < count ? (want < count - t ? want : count - t) : 0u;
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                // ticket t of head h is unit h + 8 t; idle lane number `rank` takes pixel rank % 16 of the rank / 16-th unit taken
-                if (!live && rank < got * RT_UNIT && unit_pixel(p, head + RT_WORK_HEADS * (t + rank / RT_UNIT), rank % RT_UNIT, pixel)) {
-                    live = true;
-                    frame = 0;
-                    acc = f3(0.0f, 0.0f, 0.0f);             // frame index 1 restarts accumulation (Renderer.cpp:55-56)
-                    if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
-                    path_begin(s, p, pixel, p.frame_first);
-                }
-                if (got < want) { heads_empty++; head = (head + 1u) % RT_WORK_HEADS; }
-                need = __ballot(!live);                     // what is still idle: lanes without a unit, and pixels outside the frame
-                want = (uint32_t)__popcll(need) / RT_UNIT;
+        while (need != 0ull && !share_done) {
+            if (slot == RT_UNIT) {                          // next unit of the workgroup's share
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&wg_next, 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                unit = blockIdx.x + gridDim.x * k;
+                if (unit >= p.n_units) { share_done = true; break; }
+                slot = 0;
             }
-        } else {
-            while (need != 0ull && !share_done) {
-                if (slot == RT_UNIT) {                      // next unit of the workgroup's share
-                    uint32_t k = 0;
-                    if (lane == 0) k = atomicAdd(&wg_next, 1u);
-                    k = __builtin_amdgcn_readfirstlane(k);
-                    unit = blockIdx.x + gridDim.x * k;
-                    if (unit >= p.n_units) { share_done = true; break; }
-                    slot = 0;
-                }
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-                const uint32_t avail = RT_UNIT - slot;
-                if (!live && rank < avail && unit_pixel(p, unit, slot + rank, pixel)) {
-                    live = true;
-                    frame = 0;
-                    acc = f3(0.0f, 0.0f, 0.0f);
-                    if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
-                    path_begin(s, p, pixel, p.frame_first);
-                }
-                const uint32_t wanted = (uint32_t)__popcll(need);
-                slot += wanted < avail ? wanted : avail;
-                need = __ballot(!live);                     // lanes beyond this unit, and lanes whose pixel fell outside the frame
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            const uint32_t avail = RT_UNIT - slot;
+            if (!live && rank < avail && unit_pixel(p, unit, slot + rank, pixel)) {
+                live = true;
+                frame = 0;
+                acc = f3(0.0f, 0.0f, 0.0f);                 // frame index 1 restarts accumulation (Renderer.cpp:55-56)
+                if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+                path_begin(s, p, pixel, p.frame_first);
             }
+            const uint32_t wanted = (uint32_t)__popcll(need);
+            slot += wanted < avail ? wanted : avail;
+            need = __ballot(!live);                         // lanes beyond this unit, and lanes whose pixel fell outside the frame
         }
         if (__ballot(live) == 0ull) break;                  // nothing in flight and nothing left to take
         n_iterations++;
         // The two workgroups of a CU own equal shares, but instruction issue favours the older wave, so one of them would
         // finish at half time and leave the other with half the waves per SIMD.  Issue priority alternates between the
         // two halves of the grid every iteration, which keeps them abreast.
-        if (!DYNAMIC) {
-            if ((n_iterations ^ (blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-
-        // ---- rays the tree cannot prune (a zero direction component): the wave walks the tree for them, one at a time
-        bool have_mesh_hit = false;
-        Hit mesh_hit; mesh_hit.t = FLT_MAX; mesh_hit.id = -1; mesh_hit.u = 0.0f; mesh_hit.v = 0.0f;
-        if (MODE == RT_MODE_MESH || MODE == RT_MODE_BOTH) {
-            bool unprunable = live && s.bounce < p.bounces && s.D.x == 0.0f;
-            // primary column rays were resolved for the whole frame by the pre-pass: re-run the winning triangle test for u, v
-            if (unprunable && s.bounce == 0 && s.column_slot != 0u && p.column_best && (*p.column_flags & 1u) == 0u) {
-                const unsigned long long key = p.column_best[s.column_slot - 1u];
-                if (key != ~0ull) {
-                    const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
-                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                    float tt, u, v;
-                    tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
-                    mesh_hit.t = tt; mesh_hit.u = u; mesh_hit.v = v; mesh_hit.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
-                }
-                have_mesh_hit = true;
-                unprunable = false;
-            }
-            // a parked path comes back with its hit (unless a decision of its walk depended on t: then it is walked here)
-            if (DYNAMIC && parked_hit_ready) {
-                parked_hit_ready = false;
-                if (unprunable && (p.park_flags[lane] & 1u) == 0u) {
-                    const unsigned long long key = p.park_best[lane];
-                    if (key != ~0ull) {
-                        const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
-                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-                        float tt, u, v;
-                        tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
-                        mesh_hit.t = tt; mesh_hit.u = u; mesh_hit.v = v; mesh_hit.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
-                    }
-                    have_mesh_hit = true;
-                    unprunable = false;
-                }
-            }
-            // in a large tree such a walk takes one wave a large part of a second while the chip idles: park the path (the
-            // lane takes other pixels), let whole-chip kernels find its hit after this launch, finish it in a resume launch
-            if (DYNAMIC && unprunable && !p.resume && p.n_nodes >= p.park_min_nodes) {
-                const uint32_t slot = atomicAdd(p.park_count, 1u);
-                if (slot < RT_PARK_SLOTS) {
-                    float4* q = p.park_paths + RT_PARK_WORDS * slot;
-                    q[0] = make_float4(s.O.x, s.O.y, s.O.z, __uint_as_float(s.column_slot));
-                    q[1] = make_float4(s.D.x, s.D.y, s.D.z, __uint_as_float(s.bounce));
-                    q[2] = make_float4(s.contribution.x, s.contribution.y, s.contribution.z, __uint_as_float(pixel));
-                    q[3] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, __uint_as_float(frame));
-                    q[4] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-                    q[5] = make_float4(__uint_as_float((uint32_t)s.rng), __uint_as_float((uint32_t)(s.rng >> 32)), 0.0f, 0.0f);
-                    live = false; unprunable = false;
-                }
-            }
-            unsigned long long todo = __ballot(unprunable);
-            while (todo != 0ull) {
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1ull;
-                const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
-                const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
-                const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
-                Hit h;
-                uint32_t cn = 0, ct = 0;
-                const bool ok = trace_mesh_cooperative<STATS>(p, O, D, invD, lane, h, cn, ct);
-                if (ok) {
-                    if ((int)lane == src) { have_mesh_hit = true; mesh_hit = h; }
-                    n_nodes += cn; n_tris += ct;            // counted by the lanes that did the work
-                }
-            }
-        }
+        if ((n_iterations ^ (blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
 
         // ---- one bounce for every lane with a path
-        uint32_t lane_steps = 0;
         if (live) {
             int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
-            const uint32_t steps_before = n_nodes + n_tris;
-            const bool ended = path_step<MODE, STATS, ORDERED, LDS_SCENE>(s, p, lds, id_out, have_mesh_hit, mesh_hit, n_rays, n_nodes, n_tris);
-            if (STATS) { lane_steps = n_nodes + n_tris - steps_before; path_steps += lane_steps; }
+            const bool ended = path_step<LDS_SCENE>(s, p, lds, id_out, n_rays);
             if (ended) {
                 if (id_out && p.bounces == 0) *id_out = -1;
                 acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
                 frame++;
                 if (frame < p.n_frames) path_begin(s, p, pixel, p.frame_first + frame);
-                else {
-                    // the unused fourth component carries, from the counting kernels, the node + triangle steps of the pixel's last path
-                    p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, STATS ? (float)path_steps : 0.0f); live = false;
-                }
-                path_steps = 0;
+                else { p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, 0.0f); live = false; }
             }
-        }
-        if (STATS) {                                        // how unevenly the lanes of this iteration were loaded
-            uint32_t mx = lane_steps, sm = lane_steps;
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint32_t o = __shfl_xor(mx, off); mx = mx > o ? mx : o;
-                sm += __shfl_xor(sm, off);
-            }
-            steps_max_sum += mx; steps_sum += sm;
         }
     }
 
-    // Sphere frames without the 3x3 filter: the workgroup resolves its own share of the image as soon as its last wave is
+    // Frames without the 3x3 filter: the workgroup resolves its own share of the image as soon as its last wave is
     // done (Renderer.cpp:68-79).  The sums were just written by this CU (L2-resident), every lane is busy, and the work fills
     // the time in which other workgroups still trace -- instead of a separate pass over the whole frame after the launch.
-    if (!DYNAMIC && p.fuse_resolve) {
+    if (p.fuse_resolve) {
         __syncthreads();
         const uint32_t share = p.n_units > blockIdx.x ? (p.n_units - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0u;
         const float div = (float)(p.frame_first + p.n_frames - 1u);
@@ -1186,7 +998,277 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
     if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
-        wc[3] = steps_max_sum; wc[4] = steps_sum;
+        wc[3] = 0; wc[4] = 0;
+    }
+    // work counters: one slot group per wave, summed on the host when read
+    if (p.counters) {
+        unsigned long long* slot = p.counters + 4 * (size_t)wave;
+        uint32_t r = n_rays;
+        for (int off = 32; off > 0; off >>= 1) r += __shfl_down(r, off);
+        if (lane == 0) {
+            slot[0] += (unsigned long long)r;
+            slot[3] += (unsigned long long)r * p.n_spheres;
+        }
+    }
+}
+
+// ---- tree scenes: traversal decoupled from the bounce loop ---------------------------------------------------------------
+// The lanes of a wave walk the tree for very different numbers of steps (most primary rays miss the root box or stop after a
+// few nodes; a few paths take hundreds of steps per bounce).  If every bounce ran to completion before the wave moved on, each
+// wave would spend most of its trips with a handful of lanes busy.  Here a lane's walk is a resumable state (node cursor, leaf-
+// record cursor, closest hit so far) that lives across the iterations of the wave's main loop, and each iteration runs the
+// walk only until half of the lanes that were walking have finished.  Those are shaded, get their next ray or their next
+// pixel, and join the unfinished walks in the next slice.  Every lane makes exactly the steps of KDTreeCPU::intersect for its
+// ray, in the same order, so the results do not change -- only which lanes keep each other company.
+// ORDERED = false: the walk of KDTreeCPU::intersect itself (node array 0 is the reference's preorder).
+// ORDERED = true : node array number (direction.x < 0) + 2 (direction.y < 0) + 4 (direction.z < 0) holds the same tree in
+// the preorder that puts, at every node, the child on the near side of this ray first; boxes, triangle tests and the
+// pruning rule are unchanged, so once a hit is known almost everything behind it is pruned.  Equal t is resolved to the
+// smaller leaf-record index, i.e. to the triangle the reference order reaches first.
+constexpr uint32_t PH_IDLE = 0u, PH_BEGIN = 1u, PH_WALK = 2u, PH_SHADE = 3u;
+constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;
+
+template <int MODE, bool STATS, bool ORDERED>
+__device__ __forceinline__ void tree_body(const RtParams& p)
+{
+    __shared__ SceneLds lds;                                // not used: tree scenes read the closest-hit tables from HBM
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
+    uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
+    unsigned long long clock_start = 0, trips = 0, lane_trips = 0; uint32_t n_iterations = 0;
+    const bool clocked = p.wave_clock != nullptr && !p.resume;
+    if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
+
+    uint32_t phase = PH_IDLE;
+    uint32_t pixel = 0, frame = 0, path_steps = 0;
+    F3 acc = f3(0.0f, 0.0f, 0.0f);
+    Path s;
+    s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
+    // the bounce in flight: sphere hit, closest triangle so far, cursors of the walk
+    float tS = FLT_MAX; int iS = -1;
+    Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
+    uint32_t wnode = 0, wrec = RT_NO_REC, wbest = RT_NO_REC, wsteps = 0;
+    F3 winvD = f3(0.0f, 0.0f, 0.0f);
+    const float4* wnodes = p.nodes;
+    const uint32_t end = p.n_nodes;
+
+    bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
+    if (p.resume) {
+        heads_empty = RT_WORK_HEADS;                        // no units: only the parked paths are finished
+        const uint32_t n_parked = *p.park_count < RT_PARK_SLOTS ? *p.park_count : RT_PARK_SLOTS;
+        if (wave != 0u || n_parked == 0u) return;
+        if (lane < n_parked) {
+            const float4* q = p.park_paths + RT_PARK_WORDS * lane;
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            s.O = f3(q0.x, q0.y, q0.z); s.column_slot = __float_as_uint(q0.w);
+            s.D = f3(q1.x, q1.y, q1.z); s.bounce = __float_as_uint(q1.w);
+            s.contribution = f3(q2.x, q2.y, q2.z); pixel = __float_as_uint(q2.w);
+            s.finalColor = f3(q3.x, q3.y, q3.z); frame = __float_as_uint(q3.w);
+            acc = f3(q4.x, q4.y, q4.z);
+            s.rng = ((unsigned long long)__float_as_uint(q5.y) << 32) | (unsigned long long)__float_as_uint(q5.x);
+            phase = PH_BEGIN; parked_hit_ready = true;
+        }
+    }
+
+    for (;;) {
+        // ---- give idle lanes pixels while there are units left: whole units, one per 16 idle lanes, one atomic per refill
+        unsigned long long need = __ballot(phase == PH_IDLE);
+        uint32_t want = (uint32_t)__popcll(need) / RT_UNIT;
+        while (want != 0u && heads_empty < RT_WORK_HEADS) {
+            const uint32_t count = head_count(p, head);
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(p.work_heads + head * RT_HEAD_STRIDE, want);
+            t = __builtin_amdgcn_readfirstlane(t);
+            const uint32_t got = t < count ? (want < count - t ? want : count - t) : 0u;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            // ticket t of head h is unit h + 8 t; idle lane number `rank` takes pixel rank % 16 of the rank / 16-th unit taken
+            if (phase == PH_IDLE && rank < got * RT_UNIT && unit_pixel(p, head_unit(p, head, t + rank / RT_UNIT), rank % RT_UNIT, pixel)) {
+                phase = PH_BEGIN;
+                frame = 0;
+                acc = f3(0.0f, 0.0f, 0.0f);                 // frame index 1 restarts accumulation (Renderer.cpp:55-56)
+                if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+                path_begin(s, p, pixel, p.frame_first);
+            }
+            if (got < want) { heads_empty++; head = (head + 1u) % RT_WORK_HEADS; }
+            need = __ballot(phase == PH_IDLE);              // what is still idle: lanes without a unit, and pixels outside the frame
+            want = (uint32_t)__popcll(need) / RT_UNIT;
+        }
+        if (__ballot(phase != PH_IDLE) == 0ull) break;      // nothing in flight and nothing left to take
+        n_iterations++;
+
+        // ---- lanes whose path needs its next ray traced (Renderer.cpp:149-159)
+        {
+            const bool begin = phase == PH_BEGIN;
+            bool start = begin && s.bounce < p.bounces;     // else "for (i = 0; i < Bounces; i++)" with Bounces == 0: ends below
+            bool have_hit = false;
+            if (start) { th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f; }
+            // rays the tree cannot prune (direction.x == 0): answered by the pre-pass, by the whole-chip kernels, or by this wave
+            bool unprunable = start && s.D.x == 0.0f;
+            if (unprunable && s.bounce == 0 && s.column_slot != 0u && p.column_best && (*p.column_flags & 1u) == 0u) {
+                // primary column rays were resolved for the whole frame by the pre-pass: re-run the winning triangle test for u, v
+                const unsigned long long key = p.column_best[s.column_slot - 1u];
+                if (key != ~0ull) {
+                    const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    float tt, u, v;
+                    tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
+                    th.t = tt; th.u = u; th.v = v; th.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
+                }
+                have_hit = true;
+                unprunable = false;
+            }
+            // a parked path comes back with its hit (unless a decision of its walk depended on t: then it is walked here)
+            if (parked_hit_ready) {
+                parked_hit_ready = false;
+                if (unprunable && (p.park_flags[lane] & 1u) == 0u) {
+                    const unsigned long long key = p.park_best[lane];
+                    if (key != ~0ull) {
+                        const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                        float tt, u, v;
+                        tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
+                        th.t = tt; th.u = u; th.v = v; th.id = (int32_t)(__float_as_uint(r2.y) & 0x7FFFFFFFu);
+                    }
+                    have_hit = true;
+                    unprunable = false;
+                }
+            }
+            // in a large tree such a walk takes one wave a large part of a second while the chip idles: park the path (the
+            // lane takes other pixels), let whole-chip kernels find its hit after this launch, finish it in a resume launch
+            if (unprunable && !p.resume && p.n_nodes >= p.park_min_nodes) {
+                const uint32_t slot = atomicAdd(p.park_count, 1u);
+                if (slot < RT_PARK_SLOTS) {
+                    float4* q = p.park_paths + RT_PARK_WORDS * slot;
+                    q[0] = make_float4(s.O.x, s.O.y, s.O.z, __uint_as_float(s.column_slot));
+                    q[1] = make_float4(s.D.x, s.D.y, s.D.z, __uint_as_float(s.bounce));
+                    q[2] = make_float4(s.contribution.x, s.contribution.y, s.contribution.z, __uint_as_float(pixel));
+                    q[3] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, __uint_as_float(frame));
+                    q[4] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+                    q[5] = make_float4(__uint_as_float((uint32_t)s.rng), __uint_as_float((uint32_t)(s.rng >> 32)), 0.0f, 0.0f);
+                    phase = PH_IDLE; start = false; unprunable = false;
+                }
+            }
+            unsigned long long todo = __ballot(unprunable);
+            while (todo != 0ull) {                          // the whole wave walks the tree for them, one at a time
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1ull;
+                const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
+                const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
+                const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+                Hit h;
+                uint32_t cn = 0, ct = 0;
+                const bool ok = trace_mesh_cooperative<STATS>(p, O, D, invD, lane, h, cn, ct);
+                if (ok) {
+                    if ((int)lane == src) { have_hit = true; th = h; }
+                    n_nodes += cn; n_tris += ct;            // counted by the lanes that did the work
+                }
+            }
+            if (start) {
+                s.bounce++;
+                n_rays++;
+                tS = FLT_MAX; iS = -1;
+                if (MODE == RT_MODE_BOTH) trace_spheres(p, s.O, s.D, tS, iS);
+                if (have_hit || end == 0u) phase = PH_SHADE;
+                else {
+                    winvD = f3(1.0f / s.D.x, 1.0f / s.D.y, 1.0f / s.D.z);          // Renderer.cpp:151
+                    wnodes = p.nodes;
+                    if (ORDERED) {
+                        const uint32_t octant = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
+                        wnodes += (size_t)octant * 2u * (size_t)p.n_nodes;
+                    }
+                    wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
+                    phase = PH_WALK;
+                }
+            } else if (begin && phase == PH_BEGIN) {
+                phase = PH_SHADE;                           // no bounces at all: the path ends with its initial colour
+            }
+        }
+
+        // ---- a slice of the walks (KDTreeCPU.cpp:640-708): one node or one leaf record per lane and trip
+        {
+            unsigned long long walking = __ballot(phase == PH_WALK);
+            const uint32_t leave_at = (uint32_t)__popcll(walking) >> 1;
+            // a long walk is a chain of dependent loads: its wave asks for issue priority, so that the few long rays that
+            // decide when the frame ends are not queued behind the bulk of short ones
+            if (__ballot(phase == PH_WALK && wsteps >= RT_LONG_WALK) != 0ull) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+            while ((uint32_t)__popcll(walking) > leave_at) {
+                if (STATS) { trips++; lane_trips += (unsigned long long)__popcll(walking); }
+                if (phase == PH_WALK) {
+                    // One read of RT_WALK_FETCH float4 at the cursor per trip.  Descending goes to the next node in memory
+                    // and a leaf's records are consecutive, so the read holds the next two nodes / the next record as well:
+                    // up to three node steps or two record steps are made from it, which shortens the chain of dependent
+                    // loads that a long walk is.
+                    const bool at_node = wrec == RT_NO_REC;
+                    const float4* a = at_node ? wnodes + 2 * (size_t)wnode : p.leafrecs + 3 * (size_t)wrec;
+                    const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5];
+                    static_assert(RT_WALK_FETCH == 6, "the walk reads six float4 per trip");
+                    // returns true when the walk went down to the next node in memory
+                    auto node_step = [&](float4 n0, float4 n1) -> bool {
+                        wsteps++;
+                        if (STATS) n_nodes++;
+                        float tNear;
+                        const bool box = slab_test(n0, n1, s.O, winvD, tNear);
+                        // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
+                        const bool descend = box && !(tNear > th.t);
+                        const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+                        if (descend && leaf_first == RT_LEAF_INTERIOR) { wnode = wnode + 1; return true; }
+                        wnode = __float_as_uint(n0.w);      // skip link: first node after this subtree
+                        if (descend && leaf_first >= 0) wrec = (uint32_t)leaf_first;
+                        return false;
+                    };
+                    // returns true when the leaf has more records
+                    auto rec_step = [&](float4 r0, float4 r1, float4 r2) -> bool {
+                        wsteps++;
+                        if (STATS) n_tris++;
+                        const uint32_t tag = __float_as_uint(r2.y);
+                        float tt, u, v;
+                        if (tri_test(r0, r1, r2, s.O, s.D, tt, u, v) && (tt < th.t || (ORDERED && tt == th.t && wrec < wbest))) {
+                            th.t = tt; th.id = (int32_t)(tag & 0x7FFFFFFFu); th.u = u; th.v = v; wbest = wrec;
+                        }
+                        const bool more = (tag & 0x80000000u) == 0u;
+                        wrec = more ? wrec + 1u : RT_NO_REC;
+                        return more;
+                    };
+                    if (at_node) {
+                        if (node_step(q0, q1) && node_step(q2, q3)) node_step(q4, q5);
+                    } else {
+                        if (rec_step(q0, q1, q2)) rec_step(q3, q4, q5);
+                    }
+                    if (wrec == RT_NO_REC && wnode >= end) phase = PH_SHADE;
+                }
+                walking = __ballot(phase == PH_WALK);
+            }
+        }
+
+        // ---- the lanes whose ray is traced: the rest of the bounce (Renderer.cpp:160-226)
+        if (phase == PH_SHADE) {
+            int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
+            bool ended = true;
+            if (p.bounces != 0u) ended = shade_hit<MODE, false>(s, p, lds, id_out, s.bounce == 1u, s.bounce >= p.bounces, tS, iS, th);
+            if (STATS) path_steps += wsteps;
+            wsteps = 0;
+            phase = PH_BEGIN;
+            if (ended) {
+                if (id_out && p.bounces == 0) *id_out = -1;
+                acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
+                frame++;
+                if (frame < p.n_frames) path_begin(s, p, pixel, p.frame_first + frame);
+                else {
+                    // the unused fourth component carries, from the counting kernels, the node + triangle steps of the pixel's last path
+                    p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, STATS ? (float)path_steps : 0.0f); phase = PH_IDLE;
+                }
+                path_steps = 0;
+            }
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    if (clocked && lane == 0) {
+        unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
+        wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
+        wc[3] = trips; wc[4] = lane_trips;                  // lane balance = lane_trips / (64 trips)
     }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
@@ -1209,14 +1291,14 @@ __device__ __forceinline__ void trace_body(const RtParams& p)
 template <bool STATS, bool LDS_SCENE>
 __global__ __launch_bounds__(RT_SPHERE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void rt_trace_spheres_kernel(RtParams p)
 {
-    trace_body<RT_MODE_SPHERES, STATS, false, LDS_SCENE>(p);
+    sphere_body<STATS, LDS_SCENE>(p);
 }
 
 template <int MODE, bool STATS, bool ORDERED>
 __global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
 {
     // tree scenes keep the closest-hit lookups in HBM: these kernels are bound by registers (waves per SIMD), not by those loads
-    trace_body<MODE, STATS, ORDERED, false>(p);
+    tree_body<MODE, STATS, ORDERED>(p);
 }
 
 // Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
