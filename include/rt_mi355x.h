@@ -170,10 +170,10 @@ int rt_set_stats(rt_ctx*, int on);
 int rt_read_counters(rt_ctx*, rt_counters* out);
 int rt_reset_counters(rt_ctx*);
 /* Diagnostics.  rt_set_stats(ctx, flags): bit 0 = count nodes / triangles (the counting kernels), bit 1 = record, per wave
-   of the trace launch, 5 values: the 100 MHz device clock at its start and end, the bounce-loop iterations it made and,
-   when bit 0 is set as well, the sum over iterations of the busiest lane's node + triangle steps and the sum of all
-   lanes' steps (their ratio / 64 = how evenly the lanes were loaded).  out holds 5 * max_waves values; the number of
-   waves written is returned through *n_waves. */
+   of the trace launch, 6 values: the 100 MHz device clock at its start and end, the main-loop iterations it made and, in
+   tree scenes, the trips of its walk loop (one read at each walking lane's cursor per trip), the sum over those trips of
+   the lanes that were walking (counting kernels only; / (64 x trips) = how full the trips were) and the clock ticks spent
+   inside the walk loop.  out holds 6 * max_waves values; the number of waves written is returned through *n_waves. */
 int rt_read_wave_clock(rt_ctx*, uint64_t* out, uint32_t max_waves, uint32_t* n_waves);
 int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
 int rt_reset_kernel_time(rt_ctx*);

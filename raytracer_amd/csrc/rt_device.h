@@ -15,8 +15,14 @@
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_WORDS 6            // float4 per parked path
 #define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
+#ifndef RT_SLICE_LEAVE
+#define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left */
+#endif
+#ifndef RT_COOP_LANES
+#define RT_COOP_LANES 2            /* a wave with at most this many walks left lends all its lanes to one walk at a time */
+#endif
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
-#define RT_WAVE_CLOCK_WORDS 5
+#define RT_WAVE_CLOCK_WORDS 6
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
 #define RT_HEAD_STRIDE 32          // words between heads
 #define RT_INLINE_SPHERES 32       // spheres carried in the kernel arguments (scalar loads); more go through HBM
@@ -74,8 +80,8 @@ struct RtParams {
     float4* image;
     int32_t* primary_ids;                   // optional
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
-    unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave (counting kernels only): start, end (100 MHz clock), loop
-                                            // iterations, sum over iterations of the busiest lane's node + triangle steps, sum of all lanes' steps
+    unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
+                                            // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop
     unsigned long long* column_stats;       // 2: nodes / triangles the reference's walk spends on the column rays
     // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records

@@ -357,6 +357,97 @@ __device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, 
     return true;
 }
 
+// Wave-wide inclusive prefix maximum / minimum in six data-parallel-primitive steps (shifts inside each row of 16 lanes, then
+// the last lane of a row broadcast to the following rows) -- no round trips through the LDS crossbar.  Lanes without a source
+// keep the identity (0 for the unsigned maximum, +inf for the float minimum).
+__device__ __forceinline__ uint32_t wave_prefix_max(uint32_t x)
+{
+    uint32_t o;
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = x > o ? x : o;      // row_shr:1
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = x > o ? x : o;      // row_shr:2
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = x > o ? x : o;      // row_shr:4
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = x > o ? x : o;      // row_shr:8
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = x > o ? x : o;      // row_bcast:15 into rows 1, 3
+    o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = x > o ? x : o;      // row_bcast:31 into rows 2, 3
+    return x;
+}
+__device__ __forceinline__ float wave_min(float v)            // wave-uniform result; no NaN among the inputs
+{
+    const int inf = 0x7F800000;
+    float x = v, o;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x111, 0xf, 0xf, false)); x = o < x ? o : x;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x112, 0xf, 0xf, false)); x = o < x ? o : x;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x114, 0xf, 0xf, false)); x = o < x ? o : x;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x118, 0xf, 0xf, false)); x = o < x ? o : x;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x142, 0xa, 0xf, false)); x = o < x ? o : x;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(x), 0x143, 0xc, 0xf, false)); x = o < x ? o : x;
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+// The same idea for an ordinary ray whose wave has (almost) nothing else to do: at the end of a frame a wave is left with one
+// or two long walks, each a chain of hundreds of dependent reads, and 62 idle lanes.  The wave then walks for one ray at a time:
+// each lane tests one node of a 64-node window of the preorder array against the closest hit known when the window starts, the
+// prefix maximum of the rejected nodes' skip links tells which nodes the walk reaches, reached leaves are tested lane-parallel,
+// and the closest t is re-reduced for the next window.  Pruning with the t of the window start instead of the t of the moment
+// visits a superset of the leaves the one-lane walk visits; a triangle the one-lane walk would have found in a leaf it visits is
+// found here in the same leaf with the same arithmetic, so the closest hit is the same, with ties again resolved to the
+// smallest record index.  `start`: the node cursor of the walk; hit / best_rec: its closest hit so far, in and out (all
+// arguments wave-uniform).
+__device__ __forceinline__ void walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
+                                                 Hit& hit, uint32_t& best_rec)
+{
+    float t = hit.t, hu = hit.u, hv = hit.v;                // lane-local closest hit; every lane starts from the ray's
+    int32_t tri = hit.id;
+    uint32_t rec_best = best_rec;
+    float t_prune = hit.t;                                  // wave-uniform
+    uint32_t base = start, killed_to = start;
+    const uint32_t end = p.n_nodes;
+    while (base < end) {
+        const uint32_t j = base + lane;
+        const bool valid = j < end;
+        float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+        if (valid) { n0 = nodes[2 * (size_t)j]; n1 = nodes[2 * (size_t)j + 1]; }
+        float tNear;
+        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const bool descend = valid && box && !(tNear > t_prune);
+        const uint32_t skip = __float_as_uint(n0.w);
+        const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+        // ends of the rejected subtrees up to and including this lane's node; a node that is not rejected contributes nothing,
+        // so for it "up to and including" is "before"
+        const uint32_t pm = wave_prefix_max((valid && !descend) ? skip : 0u);
+        const uint32_t limit = pm > killed_to ? pm : killed_to;
+        if (j >= limit && descend && leaf_first >= 0) {
+            uint32_t rec_index = (uint32_t)leaf_first;
+            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
+            float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            for (;;) {
+                const float4 q0 = rec[3], q1 = rec[4], q2 = rec[5];         // the next record (or padding) is in flight during the test
+                rec += 3;
+                const uint32_t tag = __float_as_uint(r2.y);
+                float tt, u, v;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v) && (tt < t || (tt == t && rec_index < rec_best))) {
+                    t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; rec_best = rec_index;
+                }
+                ++rec_index;
+                if (tag & 0x80000000u) break;
+                r0 = q0; r1 = q1; r2 = q2;
+            }
+        }
+        const uint32_t window_kill = (uint32_t)__builtin_amdgcn_readlane((int)pm, 63);
+        if (window_kill > killed_to) killed_to = window_kill;
+        base += 64u;
+        if (killed_to > base) base = killed_to;
+        t_prune = wave_min(t);
+    }
+    for (int off = 32; off > 0; off >>= 1) {                // lane winners: smallest t, then smallest record index
+        const float ot = __shfl_xor(t, off); const uint32_t orec = __shfl_xor(rec_best, off);
+        const int32_t otri = __shfl_xor(tri, off); const float ou = __shfl_xor(hu, off), ov = __shfl_xor(hv, off);
+        if (ot < t || (ot == t && orec < rec_best)) { t = ot; rec_best = orec; tri = otri; hu = ou; hv = ov; }
+    }
+    hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
+    best_rec = rec_best;
+}
+
 // Util::RandomUnitVector (Renderer.h:46-54)
 __device__ __forceinline__ F3 random_unit_vector(unsigned long long& rng)
 {
@@ -998,7 +1089,7 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
     if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
-        wc[3] = 0; wc[4] = 0;
+        wc[3] = 0; wc[4] = 0; wc[5] = 0;
     }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
@@ -1036,7 +1127,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
-    unsigned long long clock_start = 0, trips = 0, lane_trips = 0; uint32_t n_iterations = 0;
+    unsigned long long clock_start = 0, trips = 0, lane_trips = 0, walk_ticks = 0; uint32_t n_iterations = 0;
     const bool clocked = p.wave_clock != nullptr && !p.resume;
     if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
 
@@ -1188,13 +1279,36 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         // ---- a slice of the walks (KDTreeCPU.cpp:640-708): one node or one leaf record per lane and trip
         {
             unsigned long long walking = __ballot(phase == PH_WALK);
-            const uint32_t leave_at = (uint32_t)__popcll(walking) >> 1;
+            const uint32_t leave_at = ((uint32_t)__popcll(walking) * RT_SLICE_LEAVE) >> 2;
             // a long walk is a chain of dependent loads: its wave asks for issue priority, so that the few long rays that
             // decide when the frame ends are not queued behind the bulk of short ones
             if (__ballot(phase == PH_WALK && wsteps >= RT_LONG_WALK) != 0ull) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
+            const unsigned long long slice_start = clocked ? __builtin_amdgcn_s_memrealtime() : 0ull;
             while ((uint32_t)__popcll(walking) > leave_at) {
-                if (STATS) { trips++; lane_trips += (unsigned long long)__popcll(walking); }
+                trips++;
+                if (STATS) lane_trips += (unsigned long long)__popcll(walking);
+                // a wave down to its last walks lends all its lanes to one of them at a time (the counting kernels keep the
+                // one-lane walk, whose steps are the ones the reference makes)
+                if (!STATS && (uint32_t)__popcll(walking) <= RT_COOP_LANES) {
+                    const unsigned long long at_node = __ballot(phase == PH_WALK && wrec == RT_NO_REC);
+                    if (at_node != 0ull) {
+                        const int src = __ffsll((long long)at_node) - 1;
+                        const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
+                        const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
+                        const F3 invD = f3(__shfl(winvD.x, src), __shfl(winvD.y, src), __shfl(winvD.z, src));
+                        Hit h;
+                        h.t = __shfl(th.t, src); h.id = __shfl(th.id, src); h.u = __shfl(th.u, src); h.v = __shfl(th.v, src);
+                        uint32_t best = __shfl(wbest, src);
+                        const uint32_t first = __shfl(wnode, src);
+                        const uint32_t lo = __shfl((uint32_t)(uintptr_t)wnodes, src), hi = __shfl((uint32_t)((uintptr_t)wnodes >> 32), src);
+                        const float4* nodes = (const float4*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+                        walk_cooperative(p, nodes, O, D, invD, first, lane, h, best);
+                        if ((int)lane == src) { th = h; wbest = best; wnode = end; phase = PH_SHADE; }
+                        walking = __ballot(phase == PH_WALK);
+                        continue;
+                    }
+                }
                 if (phase == PH_WALK) {
                     // One read of RT_WALK_FETCH float4 at the cursor per trip.  Descending goes to the next node in memory
                     // and a leaf's records are consecutive, so the read holds the next two nodes / the next record as well:
@@ -1240,6 +1354,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 }
                 walking = __ballot(phase == PH_WALK);
             }
+            if (clocked) walk_ticks += __builtin_amdgcn_s_memrealtime() - slice_start;
         }
 
         // ---- the lanes whose ray is traced: the rest of the bounce (Renderer.cpp:160-226)
@@ -1268,7 +1383,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
-        wc[3] = trips; wc[4] = lane_trips;                  // lane balance = lane_trips / (64 trips)
+        wc[3] = trips; wc[4] = lane_trips;                  // lane balance = lane_trips / (64 trips), counting kernels only
+        wc[5] = walk_ticks;                                 // time inside the walk slices
     }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {

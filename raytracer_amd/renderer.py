@@ -311,9 +311,9 @@ class Renderer:
         return c
 
     def read_wave_clock(self, max_waves=16384):
-        """(n, 5) uint64 per wave of the last trace launch made with set_stats(True): start, end (100 MHz ticks), iterations,
-        sum over iterations of the busiest lane's steps, sum of all lanes' steps."""
-        out = np.zeros((max_waves, 5), np.uint64)
+        """(n, 6) uint64 per wave of the last trace launch made with set_stats(2 or 3): start, end (100 MHz ticks), main-loop
+        iterations, walk-loop trips, sum over trips of the walking lanes (set_stats(3) only), ticks inside the walk loop."""
+        out = np.zeros((max_waves, 6), np.uint64)
         n = C.c_uint32()
         check(self._h, self._L.rt_read_wave_clock(self._h, ptr(out), max_waves, C.byref(n)), "rt_read_wave_clock")
         return out[:n.value]

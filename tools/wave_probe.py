@@ -39,12 +39,18 @@ per_it = dur / np.maximum(it, 1)
 print("  us per iteration     :", q(per_it))
 late = end > t0 + 0.5 * (end.max() - t0)
 print("  waves still running after half the span: %d of %d; their iterations: %s" % (late.sum(), len(wc), q(it[late])))
-if wc.shape[1] >= 5 and wc[:, 3].sum() > 0:
-    mx, sm = wc[:, 3], wc[:, 4]
-    print("  traversal steps: lane balance over the frame = %.3f (all lanes' steps / (64 x busiest lane's steps, summed over iterations))" % (sm.sum() / (64 * mx.sum())))
-    print("  busiest-lane steps per iteration:", q(mx / np.maximum(it, 1)))
-    print("  the 12 last waves: busiest-lane steps/iteration, balance:", [(int(mx[i] / max(it[i], 1)), round(sm[i] / (64 * max(mx[i], 1)), 2)) for i in order[:12]])
-    print("  us per busiest-lane step (wave duration / sum of busiest-lane steps):", q(dur / np.maximum(mx, 1)))
+if wc[:, 3].sum() > 0:
+    trips, lanes, walk = wc[:, 3], wc[:, 4], wc[:, 5] * 0.01
+    print("  walk loop: %.0f trips over all waves, %.2f us per trip, %.3f of the waves' time" % (trips.sum(), walk.sum() / trips.sum(), walk.sum() / dur.sum()))
+    print("  trips per iteration  :", q(trips / np.maximum(it, 1)))
+    if lanes.sum() > 0:
+        print("  walking lanes per trip: %.1f of 64 over the frame" % (lanes.sum() / trips.sum()))
+    print("  the 12 last waves (duration us, iterations, trips, us per trip, us outside the walk loop):",
+          [(round(dur[i], 1), int(it[i]), int(trips[i]), round(walk[i] / max(trips[i], 1), 2), round(dur[i] - walk[i], 1)) for i in order[:12]])
+    for lo, hi in [(0, 100), (100, 200), (200, 300), (300, 400), (400, 500), (500, 1e9)]:
+        m = (dur >= lo) & (dur < hi)
+        if m.any():
+            print("    waves lasting [%g, %g) us: %d, trips per wave %.0f, us per trip %.2f" % (lo, hi, m.sum(), trips[m].mean(), walk[m].sum() / max(trips[m].sum(), 1)))
 if cfg["mesh"]:
     import torch
     from raytracer_amd import dist as rtd
