@@ -20,7 +20,8 @@ for cfg in (1, 2, 3, 4, 5):
         shutil.copy(b, os.path.join(root, "profiles", "%s_cfg%d_bench.json" % (tag, cfg)))
     s = json.load(open(summ))
     for k, cs in s["counters"].items():
-        timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false" in k or "rt_trace_kernel<2, false" in k
+        # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
+        timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
         if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             traffic["config%d" % cfg] = {
                 "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
