@@ -252,6 +252,7 @@ def main():
                     "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
                     "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
                     "grazing_ties": order_ties,
+                    "near_tie_rewalks_per_frame": cnt.near_ties / max(kt.launches, 1),
                     "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
                             "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
                             "that was timed; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "

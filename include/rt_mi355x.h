@@ -63,8 +63,11 @@ enum { RT_SCENE_MESH = 0, RT_SCENE_SPHERES = 1, RT_SCENE_BOTH = 2 };
      walk stays a stackless "next node or skip link" loop).  Result = the smallest t over the leaves whose chain of
      boxes the ray hits, equal t resolved to the triangle the reference order reaches first.  That is the reference's
      result whenever every triangle is listed in each leaf whose box it overlaps (the reference builder,
-     KDTreeCPU.cpp:548-597, guarantees it); the two orders can only differ when two different triangles are hit
-     within rounding distance of each other exactly on a leaf boundary.  Far fewer nodes and triangles per ray.
+     KDTreeCPU.cpp:548-597, guarantees it), except when two different triangles are hit within rounding distance of
+     each other: then the reference's answer depends on which leaves its own order happened to prune.  The walk notices
+     such near ties (it prunes with the closest t plus that distance, so it sees both triangles) and repeats the ray
+     with KDTreeCPU::intersect's own sequence of decisions; rt_counters.near_ties counts them.  Far fewer nodes and
+     triangles per ray.
    RT_ORDER_AUTO (default): front to back when the uploaded tree's two-child nodes split their box in two along one
      axis (a KD tree, as the reference builds), otherwise the reference order. */
 enum { RT_ORDER_AUTO = 0, RT_ORDER_REFERENCE = 1, RT_ORDER_FRONT_TO_BACK = 2 };
@@ -89,8 +92,10 @@ typedef struct {
    maintained while rt_set_stats(ctx, 1); in RT_ORDER_REFERENCE they equal what KDTreeCPU::intersect visits and tests
    for the same rays.  prepass_nodes / prepass_tris are the part of those two sums that belongs to primary rays with
    direction.x == +0, which a per-frame pre-pass resolves without walking the tree ray by ray: they are what the
-   reference's walk costs for those rays, not operations the GPU performed. */
-typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris; } rt_counters;
+   reference's walk costs for those rays, not operations the GPU performed.  near_ties (always maintained): rays of the
+   front-to-back walk that hit two different triangles within rounding distance of each other and were therefore walked
+   again in the reference's order (see rt_settings.traversal). */
+typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties; } rt_counters;
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh

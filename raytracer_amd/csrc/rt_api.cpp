@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -99,6 +100,7 @@ struct rt_ctx {
 
     int n_cus = 0;
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
+    float root_center[3] = {0.0f, 0.0f, 0.0f}, root_reach = 0.0f;    // see RtParams
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
@@ -169,6 +171,8 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.column_queue_cap = rt_ctx::kColumnQueueCap;
     p.park_count = c->d_park_count.ptr; p.park_flags = c->d_park_flags.ptr; p.park_paths = c->d_park_paths.ptr; p.park_best = c->d_park_best.ptr;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
+    for (int a = 0; a < 3; ++a) p.root_center[a] = c->root_center[a];
+    p.root_reach = c->root_reach;
 }
 
 // Every material index a kernel can read must be in range: the kernels do not check.
@@ -241,7 +245,7 @@ rt_ctx* rt_create(int device_id)
         c->d_park_paths.resize(RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
-        c->d_column_stats.resize(2) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 16) != hipSuccess ||
+        c->d_column_stats.resize(3) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 24) != hipSuccess ||
         c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
         c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
         c->d_column_dirs.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_queue_count.resize(1) != hipSuccess ||
@@ -524,6 +528,16 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, c->d_reached.resize(M));
     HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
+    {
+        float reach[3] = {0.0f, 0.0f, 0.0f};
+        for (uint32_t n = 0; n < N; ++n)
+            for (int a = 0; a < 3; ++a) {
+                const float d = fabsf(kd->center[3 * (size_t)n + a] - kd->center[a]) + fabsf(kd->extent[3 * (size_t)n + a]);
+                if (d > reach[a]) reach[a] = d;
+            }
+        for (int a = 0; a < 3; ++a) c->root_center[a] = kd->center[a];
+        c->root_reach = reach[0] + reach[1] + reach[2];
+    }
     c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition;
     return RT_OK;
 }
@@ -779,9 +793,9 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     for (size_t i = 0; i < h.size(); i += 4) {
         out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
     }
-    unsigned long long cs[2] = {0, 0};
+    unsigned long long cs[3] = {0, 0, 0};
     HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
-    out->prepass_nodes = cs[0]; out->prepass_tris = cs[1];
+    out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
     return RT_OK;
 }
@@ -792,7 +806,7 @@ int rt_reset_counters(rt_ctx* c)
     if (!c->d_counters.count) return RT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 3 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 

@@ -15,6 +15,20 @@
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_WORDS 6            // float4 per parked path
 #define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
+#ifndef RT_NEAR_TIES
+#define RT_NEAR_TIES 1             /* 0 compiles the near-tie test and the repeat walk out (A/B measurements) */
+#endif
+/* Near ties of the front-to-back walk.  A box's entry distance is (centre - origin) * (1 / direction) -/+ extent * (1 / direction):
+   about three roundings of magnitude |plane - origin| * |1 / direction component|, which the kernel bounds per ray by
+   reach * steep (an overestimate by the sum over the axes); a hit distance carries the roundings of the triangle test, taken
+   as RT_TIE_REL * t.  Two different triangles hit within RT_TIE_ULPS * 2^-23 * reach * steep + RT_TIE_REL * t of each other are
+   a near tie. */
+#ifndef RT_TIE_ULPS
+#define RT_TIE_ULPS 1.0f
+#endif
+#ifndef RT_TIE_REL
+#define RT_TIE_REL 1.9073486328125e-6f   /* 2^-19 */
+#endif
 #ifndef RT_SLICE_LEAVE
 #define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left */
 #endif
@@ -82,7 +96,8 @@ struct RtParams {
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop
-    unsigned long long* column_stats;       // 2: nodes / triangles the reference's walk spends on the column rays
+    unsigned long long* column_stats;       // 3: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
+                                            // reference's order because of a near tie
     // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records
     uint32_t  column_cap;
@@ -107,6 +122,8 @@ struct RtParams {
     unsigned long long* park_best;           // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
     uint32_t* park_flags;                    // per slot, bit 0: the whole-chip result may not be used (a decision depended on t)
     uint32_t  park_min_nodes;                // park only in trees with at least this many nodes
+    float     root_center[3];                // centre of the tree's root box and the sum over the axes of the largest
+    float     root_reach;                    // |node centre - root centre| + node half-extent: bounds |box plane - point in the tree|
     int32_t   ray_slot;                      // which ray the reach / test kernels serve: -1 = the column rays, else a parked slot
     uint32_t  resume;                        // trace kernel: continue the parked paths instead of drawing units
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value

@@ -393,9 +393,11 @@ __device__ __forceinline__ float wave_min(float v)            // wave-uniform re
 // found here in the same leaf with the same arithmetic, so the closest hit is the same, with ties again resolved to the
 // smallest record index.  `start`: the node cursor of the walk; hit / best_rec: its closest hit so far, in and out (all
 // arguments wave-uniform).
-__device__ __forceinline__ void walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
-                                                 Hit& hit, uint32_t& best_rec)
+template <bool ORDERED>
+__device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
+                                                 float tol, Hit& hit, uint32_t& best_rec)
 {
+    bool near_tie = false;
     float t = hit.t, hu = hit.u, hv = hit.v;                // lane-local closest hit; every lane starts from the ray's
     int32_t tri = hit.id;
     uint32_t rec_best = best_rec;
@@ -409,7 +411,7 @@ __device__ __forceinline__ void walk_cooperative(const RtParams& p, const float4
         if (valid) { n0 = nodes[2 * (size_t)j]; n1 = nodes[2 * (size_t)j + 1]; }
         float tNear;
         const bool box = slab_test(n0, n1, O, invD, tNear);
-        const bool descend = valid && box && !(tNear > t_prune);
+        const bool descend = valid && box && !(tNear > (ORDERED && RT_NEAR_TIES ? t_prune + (tol + RT_TIE_REL * t_prune) : t_prune));
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
         // ends of the rejected subtrees up to and including this lane's node; a node that is not rejected contributes nothing,
@@ -425,8 +427,10 @@ __device__ __forceinline__ void walk_cooperative(const RtParams& p, const float4
                 rec += 3;
                 const uint32_t tag = __float_as_uint(r2.y);
                 float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v) && (tt < t || (tt == t && rec_index < rec_best))) {
-                    t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; rec_best = rec_index;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+                    const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
+                    if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + RT_TIE_REL * fminf(tt, t)) near_tie = true;
+                    if (tt < t || (tt == t && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
                 }
                 ++rec_index;
                 if (tag & 0x80000000u) break;
@@ -439,13 +443,88 @@ __device__ __forceinline__ void walk_cooperative(const RtParams& p, const float4
         if (killed_to > base) base = killed_to;
         t_prune = wave_min(t);
     }
+    const float t_own = t;
+    const int32_t tri_own = tri;
     for (int off = 32; off > 0; off >>= 1) {                // lane winners: smallest t, then smallest record index
         const float ot = __shfl_xor(t, off); const uint32_t orec = __shfl_xor(rec_best, off);
         const int32_t otri = __shfl_xor(tri, off); const float ou = __shfl_xor(hu, off), ov = __shfl_xor(hv, off);
         if (ot < t || (ot == t && orec < rec_best)) { t = ot; rec_best = orec; tri = otri; hu = ou; hv = ov; }
     }
+    // a lane whose own closest hit is another triangle within that distance of the wave's: a near tie across lanes
+    if (ORDERED && RT_NEAR_TIES && tri_own != tri && fabsf(t_own - t) <= tol + RT_TIE_REL * fminf(t_own, t)) near_tie = true;
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
     best_rec = rec_best;
+    return __ballot(near_tie) != 0ull;
+}
+
+// KDTreeCPU::intersect's own sequence of decisions for one ray (reference order, every box pruned against the closest hit of
+// the moment it is reached, a hit accepted only when strictly closer), made by the whole wave.  A window of 64 consecutive
+// nodes of the reference preorder is decided with the closest t known at its start; that is exactly what the one-lane walk
+// would have used up to the first leaf of the window that finds a closer hit.  The lane of that leaf finishes its leaf in
+// order, its result becomes the closest hit, and the next window starts right behind it; lanes behind it are recomputed.
+// A ray accepts a closer hit a few dozen times at most, so the walk takes about (nodes spanned / 64) + (hits accepted) windows
+// instead of one dependent read per node.  Used for the rays whose front-to-back walk met a near tie.
+template <bool STATS>
+__device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3 O, F3 D, F3 invD, uint32_t lane, Hit& hit,
+                                                           uint32_t& n_nodes_visited, uint32_t& n_tris_tested)
+{
+    float t_cur = FLT_MAX, hu = 0.0f, hv = 0.0f;            // wave-uniform
+    int32_t tri = -1;
+    uint32_t base = 0, killed_to = 0;
+    const uint32_t end = p.n_nodes;
+    while (base < end) {
+        const uint32_t j = base + lane;
+        const bool valid = j < end;
+        float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
+        if (valid) { n0 = p.nodes[2 * (size_t)j]; n1 = p.nodes[2 * (size_t)j + 1]; }
+        float tNear;
+        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const bool descend = valid && box && !(tNear > t_cur);
+        const uint32_t skip = __float_as_uint(n0.w);
+        const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+        const uint32_t pm = wave_prefix_max((valid && !descend) ? skip : 0u);
+        const uint32_t limit = pm > killed_to ? pm : killed_to;
+        const bool reached = valid && j >= limit;           // exact for the nodes that are not rejected, which is all that is asked below
+        float lt = t_cur, lu = 0.0f, lv = 0.0f;
+        int32_t ltri = -1;
+        bool closer = false;
+        uint32_t tested = 0;
+        if (reached && descend && leaf_first >= 0) {
+            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
+            float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            for (;;) {
+                const float4 q0 = rec[3], q1 = rec[4], q2 = rec[5];
+                rec += 3;
+                ++tested;
+                const uint32_t tag = __float_as_uint(r2.y);
+                float tt, u, v;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < lt) { lt = tt; ltri = (int32_t)(tag & 0x7FFFFFFFu); lu = u; lv = v; closer = true; }
+                if (tag & 0x80000000u) break;
+                r0 = q0; r1 = q1; r2 = q2;
+            }
+        }
+        const unsigned long long found = __ballot(closer);
+        uint32_t upto = 64u;                                // lanes of this window whose decisions stand
+        if (found != 0ull) {
+            const int f = __ffsll((long long)found) - 1;
+            t_cur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lt), f));
+            hu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lu), f));
+            hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv), f));
+            tri = __builtin_amdgcn_readlane(ltri, f);
+            upto = (uint32_t)f + 1u;
+        }
+        if (STATS) {
+            uint32_t before = __shfl_up(pm, 1);             // rejected subtrees' ends over the lanes before this one
+            if (lane == 0) before = 0u;
+            if (lane < upto && valid && j >= (before > killed_to ? before : killed_to)) n_nodes_visited++;
+            if (lane < upto) n_tris_tested += tested;
+        }
+        const uint32_t kills = (uint32_t)__builtin_amdgcn_readlane((int)pm, (int)upto - 1);
+        if (kills > killed_to) killed_to = kills;
+        base += upto;
+        if (killed_to > base) base = killed_to;
+    }
+    hit.t = t_cur; hit.id = tri; hit.u = hu; hit.v = hv;
 }
 
 // Util::RandomUnitVector (Renderer.h:46-54)
@@ -1116,7 +1195,7 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
 // the preorder that puts, at every node, the child on the near side of this ray first; boxes, triangle tests and the
 // pruning rule are unchanged, so once a hit is known almost everything behind it is pruned.  Equal t is resolved to the
 // smaller leaf-record index, i.e. to the triangle the reference order reaches first.
-constexpr uint32_t PH_IDLE = 0u, PH_BEGIN = 1u, PH_WALK = 2u, PH_SHADE = 3u;
+constexpr uint32_t PH_IDLE = 0u, PH_BEGIN = 1u, PH_WALK = 2u, PH_SHADE = 3u, PH_REDO = 4u;
 constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;
 
 template <int MODE, bool STATS, bool ORDERED>
@@ -1140,6 +1219,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     float tS = FLT_MAX; int iS = -1;
     Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
     uint32_t wnode = 0, wrec = RT_NO_REC, wbest = RT_NO_REC, wsteps = 0;
+    // front-to-back walks only: distance within which two different triangles count as a near tie, the pruning bound
+    // (closest t plus that distance), whether a near tie was seen
+    float wtol = 0.0f, wprune = FLT_MAX;
+    bool wflag = false;
     F3 winvD = f3(0.0f, 0.0f, 0.0f);
     const float4* wnodes = p.nodes;
     const uint32_t end = p.n_nodes;
@@ -1269,6 +1352,14 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         wnodes += (size_t)octant * 2u * (size_t)p.n_nodes;
                     }
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
+                    wprune = FLT_MAX; wflag = false;
+                    if (ORDERED && RT_NEAR_TIES) {
+                        // A box's entry distance is rounded differently from the hit distance of a triangle inside it: by up
+                        // to a few units in the last place of |plane - origin| / |direction component|.
+                        const float reach = ((fabsf(s.O.x - p.root_center[0]) + fabsf(s.O.y - p.root_center[1])) + fabsf(s.O.z - p.root_center[2])) + p.root_reach;
+                        const float steep = fmaxf(fabsf(winvD.x), fmaxf(fabsf(winvD.y), fabsf(winvD.z)));
+                        wtol = reach * steep * (RT_TIE_ULPS * 1.1920929e-7f);
+                    }
                     phase = PH_WALK;
                 }
             } else if (begin && phase == PH_BEGIN) {
@@ -1278,6 +1369,21 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
 
         // ---- a slice of the walks (KDTreeCPU.cpp:640-708): one node or one leaf record per lane and trip
         {
+            if (ORDERED && RT_NEAR_TIES) {                  // rays that met a near tie: the reference's own walk, by the whole wave
+                unsigned long long again = __ballot(phase == PH_REDO);
+                while (again != 0ull) {
+                    const int src = __ffsll((long long)again) - 1;
+                    again &= again - 1ull;
+                    const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
+                    const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
+                    const F3 invD = f3(__shfl(winvD.x, src), __shfl(winvD.y, src), __shfl(winvD.z, src));
+                    Hit h;
+                    uint32_t cn = 0, ct = 0;
+                    walk_reference_cooperative<STATS>(p, O, D, invD, lane, h, cn, ct);
+                    n_nodes += cn; n_tris += ct;
+                    if ((int)lane == src) { th = h; phase = PH_SHADE; }
+                }
+            }
             unsigned long long walking = __ballot(phase == PH_WALK);
             const uint32_t leave_at = ((uint32_t)__popcll(walking) * RT_SLICE_LEAVE) >> 2;
             // a long walk is a chain of dependent loads: its wave asks for issue priority, so that the few long rays that
@@ -1303,8 +1409,14 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         const uint32_t first = __shfl(wnode, src);
                         const uint32_t lo = __shfl((uint32_t)(uintptr_t)wnodes, src), hi = __shfl((uint32_t)((uintptr_t)wnodes >> 32), src);
                         const float4* nodes = (const float4*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
-                        walk_cooperative(p, nodes, O, D, invD, first, lane, h, best);
-                        if ((int)lane == src) { th = h; wbest = best; wnode = end; phase = PH_SHADE; }
+                        const float tol = ORDERED ? __shfl(wtol, src) : 0.0f;
+                        const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, h, best);
+                        if ((int)lane == src) {
+                            th = h; wbest = best; wnode = end;
+                            wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + RT_TIE_REL * h.t) : h.t;
+                            if (near_tie || wflag) { phase = PH_REDO; wflag = false; atomicAdd(p.column_stats + 2, 1ull); }
+                            else phase = PH_SHADE;
+                        }
                         walking = __ballot(phase == PH_WALK);
                         continue;
                     }
@@ -1325,7 +1437,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         float tNear;
                         const bool box = slab_test(n0, n1, s.O, winvD, tNear);
                         // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
-                        const bool descend = box && !(tNear > th.t);
+                        const bool descend = box && !(tNear > (ORDERED ? wprune : th.t));
                         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
                         if (descend && leaf_first == RT_LEAF_INTERIOR) { wnode = wnode + 1; return true; }
                         wnode = __float_as_uint(n0.w);      // skip link: first node after this subtree
@@ -1338,8 +1450,13 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         if (STATS) n_tris++;
                         const uint32_t tag = __float_as_uint(r2.y);
                         float tt, u, v;
-                        if (tri_test(r0, r1, r2, s.O, s.D, tt, u, v) && (tt < th.t || (ORDERED && tt == th.t && wrec < wbest))) {
-                            th.t = tt; th.id = (int32_t)(tag & 0x7FFFFFFFu); th.u = u; th.v = v; wbest = wrec;
+                        if (tri_test(r0, r1, r2, s.O, s.D, tt, u, v)) {
+                            const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
+                            if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + RT_TIE_REL * fminf(tt, th.t)) wflag = true;
+                            if (tt < th.t || (ORDERED && tt == th.t && wrec < wbest)) {
+                                th.t = tt; th.id = id; th.u = u; th.v = v; wbest = wrec;
+                                wprune = RT_NEAR_TIES ? tt + (wtol + RT_TIE_REL * tt) : tt;
+                            }
                         }
                         const bool more = (tag & 0x80000000u) == 0u;
                         wrec = more ? wrec + 1u : RT_NO_REC;
@@ -1350,7 +1467,15 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     } else {
                         if (rec_step(q0, q1, q2)) rec_step(q3, q4, q5);
                     }
-                    if (wrec == RT_NO_REC && wnode >= end) phase = PH_SHADE;
+                    if (wrec == RT_NO_REC && wnode >= end) {
+                        if (ORDERED && wflag) {
+                            // Two different triangles within rounding distance of each other: which of them the reference
+                            // returns depends on the leaves its own order happens to prune.  The wave walks this ray again,
+                            // in that order (before its next slice).
+                            phase = PH_REDO; wflag = false;
+                            atomicAdd(p.column_stats + 2, 1ull);
+                        } else phase = PH_SHADE;
+                    }
                 }
                 walking = __ballot(phase == PH_WALK);
             }
