@@ -212,37 +212,59 @@ struct Hit { float t; int32_t id; float u, v; };
 
 // ---- spheres: Renderer.cpp:243-271 ------------------------------------------------------------------------------
 // The reference computes t = (-b - sqrt(disc)) / (2a) for every sphere with disc >= 0 and keeps the first strictly smaller
-// positive t.  Two exact shortcuts skip work whose outcome is already decided:
+// positive t.  Exact shortcuts skip work whose outcome is already decided:
 //   * b >= 0  =>  the numerator -b - sqrt(disc) <= 0  =>  t <= 0: rejected by "t > 0";
 //   * all candidates share the positive divisor 2a and IEEE division is monotone in the numerator, so a numerator that is
-//     not below the best numerator so far cannot give a strictly smaller t: rejected by "t < closest".
-// Both leave closest / index exactly as the reference's loop would.
+//     not below the best numerator so far cannot give a strictly smaller t: rejected by "t < closest";
+//   * a numerator below the best one by more than a millionth of it gives a strictly smaller quotient (each quotient is
+//     rounded by at most half a unit in the last place, 6e-8 of its value), so the loop only tracks the best numerator and its
+//     index and divides once at the end.  Numerators closer together than that are decided by their quotients, as the
+//     reference does (the second of two equal quotients loses).
+// All of them leave closest / index exactly as the reference's loop would (closest is FLT_MAX on entry).
+struct SphereBest { float num; int index; };
+
+__device__ __forceinline__ void sphere_test(float4 sp, int i, F3 O, F3 D, float dbl_a, float four_a, SphereBest& best)
+{
+    F3 ro = O - f3(sp.x, sp.y, sp.z);
+    float b = 2.0f * dot3(ro, D);
+    float c = dot3(ro, ro) - sp.w;                         // sp.w = radius*radius, rounded once at upload
+    float disc = b * b - four_a * c;
+    // (Branches, not selects: the rays of a wave are coherent enough that whole waves skip the square root for most spheres;
+    // straight-line code measured a third slower.)
+    if (disc >= 0.0f && b < 0.0f) {
+        float num = -b - sqrt_rn(disc);
+        if (num > 0.0f && num < best.num) {
+            bool take = num < best.num * 0.999999f && num > 1e-30f;
+            if (!take) {                                    // about one candidate in a million
+                const float t = num / dbl_a;
+                take = t > 0.0f && (best.index < 0 || t < best.num / dbl_a);
+            }
+            if (take) { best.num = num; best.index = i; }
+        }
+    }
+}
+
 template <bool INLINE>
 __device__ __forceinline__ void trace_spheres_from(const RtParams& p, F3 O, F3 D, float& closest, int& index)
 {
     float a = dot3(D, D);
     float dbl_a = 2.0f * a;
     float four_a = 4.0f * a;
-    float best_num = __builtin_inff();
+    SphereBest best; best.num = __builtin_inff(); best.index = -1;
     const uint32_t n = p.n_spheres;
     if (n == 0u) return;
-    float4 next = INLINE ? p.sph_inline[0] : p.spheres[0];              // wave-uniform index: a scalar load
-    for (uint32_t i = 0; i < n; ++i) {
-        const float4 cur = next;
-        if (i + 1u < n) next = INLINE ? p.sph_inline[i + 1u] : p.spheres[i + 1u];   // in flight while this sphere is tested
-        F3 ro = O - f3(cur.x, cur.y, cur.z);
-        float b = 2.0f * dot3(ro, D);
-        float c = dot3(ro, ro) - cur.w;                    // cur.w = radius*radius, rounded once at upload
-        float disc = b * b - four_a * c;
-        // (Branches, not selects: the rays of a wave are coherent enough that whole waves skip the square root and the division
-        // for most spheres; straight-line code measured a third slower.)
-        if (disc >= 0.0f && b < 0.0f) {
-            float num = -b - sqrt_rn(disc);
-            if (num > 0.0f && num < best_num) {
-                float t = num / dbl_a;
-                if (t > 0.0f && t < closest) { closest = t; index = (int)i; best_num = num; }
-            }
-        }
+    // two spheres per trip, each read (wave-uniform index: a scalar load) while the other is tested
+    float4 even = INLINE ? p.sph_inline[0] : p.spheres[0], odd = even;
+    for (uint32_t i = 0; i < n; i += 2u) {
+        if (i + 1u < n) odd = INLINE ? p.sph_inline[i + 1u] : p.spheres[i + 1u];
+        sphere_test(even, (int)i, O, D, dbl_a, four_a, best);
+        if (i + 1u >= n) break;
+        if (i + 2u < n) even = INLINE ? p.sph_inline[i + 2u] : p.spheres[i + 2u];
+        sphere_test(odd, (int)i + 1, O, D, dbl_a, four_a, best);
+    }
+    if (best.index >= 0) {
+        const float t = best.num / dbl_a;
+        if (t > 0.0f && t < closest) { closest = t; index = best.index; }
     }
 }
 
