@@ -71,6 +71,7 @@ struct rt_ctx {
     std::vector<float> h_verts;           // kept for the tree re-layout
     std::vector<uint32_t> h_tris;
     std::vector<uint32_t> h_sphere_mat, h_tri_mat;
+    uint32_t tri_mat_max = 0, tri_mat_max_at = 0;        // largest triangle material index and a triangle that has it (checked per frame)
 
     DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image, d_dirs;
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
@@ -89,7 +90,10 @@ struct rt_ctx {
     DevBuf<uint32_t> d_column_count, d_column_pixels, d_column_flags, d_column_block, d_column_queue_count;
     DevBuf<float4> d_column_dirs, d_column_boxes;      // boxes: 16-slot, 64-slot, 256-slot arrays back to back
     DevBuf<uint2> d_column_queue;
-    DevBuf<uint32_t> d_park_count, d_park_flags;         // bounce rays the tree cannot prune, handed to whole-chip kernels
+    // bounce rays the tree cannot prune, handed to whole-chip kernels: two lists (one being resolved and resumed while the
+    // resumed paths park into the other), per-slot results, the families' slot lists
+    DevBuf<uint32_t> d_park_count, d_park_flags, d_park_list;
+    DevBuf<int32_t> d_park_info;
     DevBuf<float4> d_park_paths;
     DevBuf<unsigned long long> d_park_best;
     DevBuf<unsigned long long> d_column_best;
@@ -170,6 +174,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.column_queue = c->d_column_queue.ptr; p.column_queue_count = c->d_column_queue_count.ptr;
     p.column_queue_cap = rt_ctx::kColumnQueueCap;
     p.park_count = c->d_park_count.ptr; p.park_flags = c->d_park_flags.ptr; p.park_paths = c->d_park_paths.ptr; p.park_best = c->d_park_best.ptr;
+    p.resume_count = c->d_park_count.ptr; p.resume_paths = c->d_park_paths.ptr; p.park_list = c->d_park_list.ptr; p.park_info = c->d_park_info.ptr;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
     for (int a = 0; a < 3; ++a) p.root_center[a] = c->root_center[a];
     p.root_reach = c->root_reach;
@@ -185,9 +190,8 @@ int validate_scene(rt_ctx* c, int mode)
     }
     if (mode == RT_SCENE_MESH || mode == RT_SCENE_BOTH) {
         if (!c->n_nodes) return fail(c, RT_E_STATE, "scene_mode %d needs a KD tree (rt_set_mesh + rt_set_kdtree)", mode);
-        for (uint32_t i = 0; i < c->n_tris; ++i)
-            if (c->h_tri_mat[i] >= c->n_materials)
-                return fail(c, RT_E_ARG, "triangle %u: material index %u out of range (%u materials)", i, c->h_tri_mat[i], c->n_materials);
+        if (c->n_tris && c->tri_mat_max >= c->n_materials)
+            return fail(c, RT_E_ARG, "triangle %u: material index %u out of range (%u materials)", c->tri_mat_max_at, c->tri_mat_max, c->n_materials);
     }
     return RT_OK;
 }
@@ -240,9 +244,10 @@ rt_ctx* rt_create(int device_id)
         hipMemset(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long)) != hipSuccess ||
         c->d_wave_clock.resize((size_t)prop.multiProcessorCount * kMaxBlocksPerCu * 4 * RT_WAVE_CLOCK_WORDS) != hipSuccess ||
         hipMemset(c->d_wave_clock.ptr, 0, c->d_wave_clock.count * sizeof(unsigned long long)) != hipSuccess ||
-        c->d_park_count.resize(1) != hipSuccess || hipMemset(c->d_park_count.ptr, 0, 4) != hipSuccess ||
+        c->d_park_count.resize(2) != hipSuccess || hipMemset(c->d_park_count.ptr, 0, 8) != hipSuccess ||
         c->d_park_flags.resize(RT_PARK_SLOTS) != hipSuccess || hipMemset(c->d_park_flags.ptr, 0, 4 * RT_PARK_SLOTS) != hipSuccess ||
-        c->d_park_paths.resize(RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
+        c->d_park_list.resize(RT_PARK_FAMILIES * RT_PARK_SLOTS) != hipSuccess || c->d_park_info.resize(3 * RT_PARK_FAMILIES) != hipSuccess ||
+        c->d_park_paths.resize(2 * RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
         c->d_column_stats.resize(3) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 24) != hipSuccess ||
@@ -269,6 +274,7 @@ void rt_destroy(rt_ctx* c)
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release(); c->d_wave_clock.release(); c->d_column_stats.release(); c->d_work_heads.release();
     c->d_park_count.release(); c->d_park_flags.release(); c->d_park_paths.release(); c->d_park_best.release();
+    c->d_park_list.release(); c->d_park_info.release();
     c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
     c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
@@ -371,6 +377,8 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     c->h_verts.assign(verts, verts + 3 * (size_t)nverts);
     c->h_tris.assign(tri_idx, tri_idx + 3 * (size_t)ntris);
     c->h_tri_mat.assign(tri_mat, tri_mat + ntris);
+    c->tri_mat_max = 0; c->tri_mat_max_at = 0;
+    for (uint32_t i = 0; i < ntris; ++i) if (tri_mat[i] > c->tri_mat_max) { c->tri_mat_max = tri_mat[i]; c->tri_mat_max_at = i; }
     std::vector<float4> shade(3 * (size_t)ntris);
     for (uint32_t t = 0; t < ntris; ++t) {
         const float* n = normals9 + 9 * (size_t)t;
@@ -666,16 +674,36 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     p.fuse_resolve = fused ? 1u : 0u;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
+    const bool parking = mode != RT_SCENE_SPHERES && c->n_nodes >= c->park_min_nodes;
+    if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
-    if (mode != RT_SCENE_SPHERES && c->n_nodes >= c->park_min_nodes) {
-        // the paths the launch parked (bounce rays with direction.x == 0, rare): their hits by whole-chip kernels, then the rest of
-        // those paths by one workgroup of the trace kernel; all of it returns at once when nothing was parked
-        HIP_TRY(c, rt_launch_parked_rays(&p, c->stats ? 1 : 0, c->stream));
-        RtParams q = p; q.resume = 1;
-        HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, 1, c->stream));
-    }
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
     c->ev_head++;
+    if (parking) {
+        // The paths the launch parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a
+        // glass sphere that sits on the camera's x).  Their hits by whole-chip kernels, family by family, then the rest of those
+        // paths by a small launch of the trace kernel -- which may park again at a later bounce, into the other list: one round
+        // per bounce at most.  How many were parked decides what is launched, so the host reads that one word back.
+        uint32_t parked = 0;
+        int cur = 0;
+        HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr, sizeof parked, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (uint32_t round = 0; parked != 0; ++round) {
+            const bool last = round + 1 >= c->settings.bounces;
+            RtParams q = p;
+            q.resume_count = c->d_park_count.ptr + cur; q.resume_paths = c->d_park_paths.ptr + (size_t)cur * RT_PARK_SLOTS * RT_PARK_WORDS;
+            q.park_count = c->d_park_count.ptr + (1 - cur); q.park_paths = c->d_park_paths.ptr + (size_t)(1 - cur) * RT_PARK_SLOTS * RT_PARK_WORDS;
+            HIP_TRY(c, hipMemsetAsync(q.park_count, 0, sizeof(uint32_t), c->stream));
+            HIP_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
+            q.resume = last ? 2u : 1u;
+            const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
+            HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + 255u) / 256u, c->stream));
+            if (last) break;
+            cur = 1 - cur;
+            HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+    }
     if (!fused) HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));
     if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index + n - 1, gx, gy, c->stream));
     return RT_OK;

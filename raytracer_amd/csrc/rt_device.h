@@ -11,7 +11,9 @@
 
 #define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile
 #define RT_SPHERE_BLOCK 1024       // threads per workgroup of the sphere-scene trace kernel (16 waves sharing one unit counter in LDS)
-#define RT_PARK_SLOTS 2            // bounce rays the tree cannot prune that one frame can hand to whole-chip kernels
+#define RT_PARK_SLOTS 4096         // bounce rays the tree cannot prune that one round can hand to whole-chip kernels
+#define RT_PARK_CHUNK 1024         // ... of which this many wait in LDS at a time while the records stream past
+#define RT_PARK_FAMILIES 2         // ... grouped by (origin.x, sign of the zero): rays of a family visit the same nodes
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_WORDS 6            // float4 per parked path
 #define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
@@ -117,14 +119,19 @@ struct RtParams {
     // Bounce rays with direction.x == 0 in a large tree ("parked" paths): the trace kernel stores the path and frees the lane,
     // whole-chip kernels find the hit (same reach + test as for the column rays, one ray at a time), a one-workgroup launch of
     // the trace kernel (resume != 0) continues the paths.
-    uint32_t* park_count;                    // paths parked by this frame's trace launch (may exceed RT_PARK_SLOTS: the excess was not parked)
+    uint32_t* park_count;                    // paths parked by the running trace launch (may exceed RT_PARK_SLOTS: the excess was not parked)
     float4*   park_paths;                    // RT_PARK_WORDS float4 per slot: origin, direction, contribution, colour, {rng lo, rng hi, bounce, pixel}, {accumulated rgb, frame}
-    unsigned long long* park_best;           // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
-    uint32_t* park_flags;                    // per slot, bit 0: the whole-chip result may not be used (a decision depended on t)
+    const uint32_t* resume_count;            // the list being resolved / resumed (what the previous launch parked): same layout
+    const float4*   resume_paths;
+    unsigned long long* park_best;           // per slot of that list: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
+    uint32_t* park_flags;                    // per slot of that list, bit 0: no whole-chip result (a decision depended on t, or a third family)
+    uint32_t* park_list;                     // RT_PARK_FAMILIES x RT_PARK_SLOTS: the slots of each family
+    int32_t*  park_info;                     // per family: [f] representative slot (-1 = none), [2 + f] size, [4 + f] bit 0: visited set depends on t
     uint32_t  park_min_nodes;                // park only in trees with at least this many nodes
     float     root_center[3];                // centre of the tree's root box and the sum over the axes of the largest
     float     root_reach;                    // |node centre - root centre| + node half-extent: bounds |box plane - point in the tree|
-    int32_t   ray_slot;                      // which ray the reach / test kernels serve: -1 = the column rays, else a parked slot
-    uint32_t  resume;                        // trace kernel: continue the parked paths instead of drawing units
+    int32_t   ray_slot;                      // which rays the reach / test kernels serve: -1 = the column rays, else a family of parked rays
+    uint32_t  resume;                        // trace kernel: 0 = draw units; 1 = continue the paths of the resume list (may park again);
+                                             // 2 = the same, but rays the tree cannot prune are walked by their wave
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

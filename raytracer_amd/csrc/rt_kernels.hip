@@ -899,7 +899,7 @@ __device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v, uint32_t lane
 }
 
 // The ray the reach / test kernels work for (p.ray_slot): the column rays' representative (slot 0 of the family; `count` =
-// size of the family), or one parked bounce ray (`count` = 1).  False when there is nothing to do.
+// size of the family), or the representative of a family of parked bounce rays.  False when there is nothing to do.
 __device__ __forceinline__ bool reach_ray(const RtParams& p, F3& O, F3& D, uint32_t& count)
 {
     if (p.ray_slot < 0) {
@@ -909,9 +909,10 @@ __device__ __forceinline__ bool reach_ray(const RtParams& p, F3& O, F3& D, uint3
         O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]); D = f3(d4.x, d4.y, d4.z);
         return true;
     }
-    if ((uint32_t)p.ray_slot >= *p.park_count) return false;
-    const float4 o4 = p.park_paths[RT_PARK_WORDS * p.ray_slot], d4 = p.park_paths[RT_PARK_WORDS * p.ray_slot + 1];
-    O = f3(o4.x, o4.y, o4.z); D = f3(d4.x, d4.y, d4.z); count = 1u;
+    const int32_t rep = p.park_info[p.ray_slot];
+    if (rep < 0) return false;
+    const float4 o4 = p.resume_paths[RT_PARK_WORDS * rep], d4 = p.resume_paths[RT_PARK_WORDS * rep + 1];
+    O = f3(o4.x, o4.y, o4.z); D = f3(d4.x, d4.y, d4.z); count = (uint32_t)p.park_info[RT_PARK_FAMILIES + p.ray_slot];
     return true;
 }
 
@@ -924,7 +925,7 @@ __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
     if (p.ray_slot < 0) {
         if (gid < count) p.column_best[gid] = ~0ull;                // fresh results for this frame (grid covers column_cap)
         if (gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }
-    } else if (gid == 0u) { p.park_best[p.ray_slot] = ~0ull; p.park_flags[p.ray_slot] = 0u; }
+    }
     const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     bool box; float tNear;
     uint32_t m = column_kill_end(p, gid, O, invD, box, tNear);
@@ -981,33 +982,100 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     const bool visited = j < p.n_nodes && j >= limit;
     if (j < p.n_nodes) p.reached[j] = (visited && box) ? 1 : 0;
     // a visited box with a real t_near could be pruned by the closest t so far: then the visited set is not fixed
-    if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.ray_slot < 0 ? p.column_flags : p.park_flags + p.ray_slot, 1u);
+    if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.ray_slot < 0 ? p.column_flags : (uint32_t*)p.park_info + 2 * RT_PARK_FAMILIES + p.ray_slot, 1u);
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(__ballot(visited));
         if (lane == 0u && n) atomicAdd(&p.column_stats[0], (unsigned long long)n * count);  // every ray of the family visits these nodes
     }
 }
 
-// A parked ray against every record of the leaves it visits: the real triangle test, min (t, record index).  A fixed grid
-// strides over the records, so that the launch costs next to nothing when the slot is empty (the usual case).
+// Parked rays (direction.x == 0, see tree_body).  With an infinite inverse in x the slab test hits every box on one side of
+// origin.x and misses every box on the other, whatever y and z are, so all parked rays with the same origin.x and the same
+// sign of the zero visit the same nodes: a family.  (A glass sphere centred on the camera's x turns the whole centre column
+// of primary rays into such bounce rays: same plane, hundreds per frame.)  This kernel sorts the slots of the list being
+// resolved into at most RT_PARK_FAMILIES families; further families get no whole-chip result and are walked by their wave.
+__global__ __launch_bounds__(1024) void rt_park_group_kernel(RtParams p)
+{
+    __shared__ uint32_t key0[2], rep1, sizes[RT_PARK_FAMILIES];
+    const uint32_t n = *p.resume_count < RT_PARK_SLOTS ? *p.resume_count : RT_PARK_SLOTS;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { rep1 = 0xFFFFFFFFu; sizes[0] = sizes[1] = 0u; }
+    if (tid < 3 * RT_PARK_FAMILIES) p.park_info[tid] = tid < RT_PARK_FAMILIES ? -1 : 0;
+    if (n == 0u) return;
+    if (tid == 0) { key0[0] = __float_as_uint(p.resume_paths[0].x); key0[1] = __float_as_uint(p.resume_paths[1].x); }
+    __syncthreads();
+    for (uint32_t sl = tid; sl < n; sl += blockDim.x) {
+        const uint32_t ox = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl].x), dx = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl + 1].x);
+        if (ox != key0[0] || dx != key0[1]) atomicMin(&rep1, sl);
+    }
+    __syncthreads();
+    uint32_t k1o = 0, k1d = 0;
+    if (rep1 != 0xFFFFFFFFu) { k1o = __float_as_uint(p.resume_paths[RT_PARK_WORDS * rep1].x); k1d = __float_as_uint(p.resume_paths[RT_PARK_WORDS * rep1 + 1].x); }
+    for (uint32_t sl = tid; sl < n; sl += blockDim.x) {
+        const uint32_t ox = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl].x), dx = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl + 1].x);
+        p.park_best[sl] = ~0ull;
+        int fam = -1;
+        if (ox == key0[0] && dx == key0[1]) fam = 0;
+        else if (rep1 != 0xFFFFFFFFu && ox == k1o && dx == k1d) fam = 1;
+        p.park_flags[sl] = fam < 0 ? 1u : 0u;
+        if (fam >= 0) p.park_list[fam * RT_PARK_SLOTS + atomicAdd(&sizes[fam], 1u)] = sl;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        p.park_info[0] = 0; p.park_info[RT_PARK_FAMILIES] = (int32_t)sizes[0];
+        if (rep1 != 0xFFFFFFFFu) { p.park_info[1] = (int32_t)rep1; p.park_info[RT_PARK_FAMILIES + 1] = (int32_t)sizes[1]; }
+    }
+}
+
+// Every ray of a family against every record of the leaves the family visits: the real triangle test, min (t, record index)
+// per ray.  A fixed grid strides over the records (each read once); the family's rays wait in LDS.
 __global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p, int stats)
 {
-    F3 O, D; uint32_t count;
-    if (!reach_ray(p, O, D, count) || (p.park_flags[p.ray_slot] & 1u)) return;
-    for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r - threadIdx.x < p.n_refs; r += gridDim.x * 256u) {
-        bool use = false;
-        float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
-        if (stats) {
-            const uint32_t n = (uint32_t)__popcll(__ballot(use));
-            if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n);
+    __shared__ float4 ray_o[RT_PARK_CHUNK], ray_d[RT_PARK_CHUNK];       // origin + slot, direction
+    F3 O0, D0; uint32_t count;
+    if (!reach_ray(p, O0, D0, count)) return;
+    const uint32_t* list = p.park_list + p.ray_slot * RT_PARK_SLOTS;
+    if (p.park_info[2 * RT_PARK_FAMILIES + p.ray_slot] & 1) {          // the visited set is not fixed: no result for these rays
+        if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < count; k += 256u) p.park_flags[list[k]] = 1u;
+        return;
+    }
+    for (uint32_t first = 0; first < count; first += RT_PARK_CHUNK) {
+        const uint32_t chunk = count - first < RT_PARK_CHUNK ? count - first : RT_PARK_CHUNK;
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < chunk; k += 256u) {
+            const uint32_t sl = list[first + k];
+            const float4 o4 = p.resume_paths[RT_PARK_WORDS * sl], d4 = p.resume_paths[RT_PARK_WORDS * sl + 1];
+            ray_o[k] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(sl)); ray_d[k] = d4;
         }
-        if (!use) continue;
-        const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
-        float tt, u, v;
-        if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
-            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
-            atomicMin(&p.park_best[p.ray_slot], key);
+        __syncthreads();
+        for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r - threadIdx.x < p.n_refs; r += gridDim.x * 256u) {
+            bool use = false;
+            float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
+            if (stats) {
+                const uint32_t n = (uint32_t)__popcll(__ballot(use));
+                if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * chunk);
+            }
+            if (!use) continue;
+            const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
+            const F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+            for (uint32_t k = 0; k < chunk; ++k) {
+                const float4 o4 = ray_o[k], d4 = ray_d[k];
+                const F3 O = f3(o4.x, o4.y, o4.z), D = f3(d4.x, d4.y, d4.z);
+                // The first values of tri_test, and what they already decide without its division: u = (1 / a) * su has the sign
+                // of su * a when neither factor is tiny, and |u| >= 2 (1 - 2^-23) when |su| > 2 |a|: either way u is outside [0, 1].
+                const F3 h = cross3(D, e2);
+                const float a = dot3(e1, h);
+                const float su = dot3(O - v0, h);
+                const float aa = fabsf(a), asu = fabsf(su);
+                const bool reject = (a > -0.00001f && a < 0.00001f) || ((su < 0.0f) != (a < 0.0f) && asu > 1e-18f && aa < 1e18f) || asu > 2.0f * aa;
+                if (reject) continue;
+                float tt, u, v;
+                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
+                    atomicMin(&p.park_best[__float_as_uint(o4.w)], key);
+                }
+            }
         }
     }
 }
@@ -1250,12 +1318,14 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     const uint32_t end = p.n_nodes;
 
     bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
+    uint32_t resume_slot = 0;
     if (p.resume) {
         heads_empty = RT_WORK_HEADS;                        // no units: only the parked paths are finished
-        const uint32_t n_parked = *p.park_count < RT_PARK_SLOTS ? *p.park_count : RT_PARK_SLOTS;
-        if (wave != 0u || n_parked == 0u) return;
-        if (lane < n_parked) {
-            const float4* q = p.park_paths + RT_PARK_WORDS * lane;
+        const uint32_t n_parked = *p.resume_count < RT_PARK_SLOTS ? *p.resume_count : RT_PARK_SLOTS;
+        if (wave * 64u >= n_parked) return;
+        resume_slot = wave * 64u + lane;
+        if (resume_slot < n_parked) {
+            const float4* q = p.resume_paths + RT_PARK_WORDS * resume_slot;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
             s.O = f3(q0.x, q0.y, q0.z); s.column_slot = __float_as_uint(q0.w);
             s.D = f3(q1.x, q1.y, q1.z); s.bounce = __float_as_uint(q1.w);
@@ -1317,8 +1387,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             // a parked path comes back with its hit (unless a decision of its walk depended on t: then it is walked here)
             if (parked_hit_ready) {
                 parked_hit_ready = false;
-                if (unprunable && (p.park_flags[lane] & 1u) == 0u) {
-                    const unsigned long long key = p.park_best[lane];
+                if (unprunable && (p.park_flags[resume_slot] & 1u) == 0u) {
+                    const unsigned long long key = p.park_best[resume_slot];
                     if (key != ~0ull) {
                         const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
                         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
@@ -1332,7 +1402,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             }
             // in a large tree such a walk takes one wave a large part of a second while the chip idles: park the path (the
             // lane takes other pixels), let whole-chip kernels find its hit after this launch, finish it in a resume launch
-            if (unprunable && !p.resume && p.n_nodes >= p.park_min_nodes) {
+            if (unprunable && p.resume != 2u && p.n_nodes >= p.park_min_nodes) {
                 const uint32_t slot = atomicAdd(p.park_count, 1u);
                 if (slot < RT_PARK_SLOTS) {
                     float4* q = p.park_paths + RT_PARK_WORDS * slot;
@@ -1573,7 +1643,6 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t fr
     const uint32_t y = band * RT_TILE + (wave >> 1) * 8u + (lane >> 3);
     // the trace kernel that produced this frame has drained the unit queue: zero its heads for the next trace launch
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.park_count = 0u;
     if (x < p.width && y < p.height) {
         const uint32_t pixel = y * p.width + x;
         float4 a = p.accum[pixel];
@@ -1689,13 +1758,14 @@ extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hip
     return hipGetLastError();
 }
 
-// After a trace launch over a large tree: the hits of the paths it parked, slot by slot (each kernel returns at once when the
-// slot is empty).  The resume launch of the trace kernel follows.
+// The hits of the parked paths of the resume list, family by family: visited nodes, then every record of a visited leaf
+// against every ray of the family.  The resume launch of the trace kernel follows.
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s)
 {
     RtParams q = *p;
-    for (int slot = 0; slot < RT_PARK_SLOTS; ++slot) {
-        q.ray_slot = slot;
+    hipLaunchKernelGGL(rt_park_group_kernel, dim3(1), dim3(1024), 0, s, q);
+    for (int family = 0; family < RT_PARK_FAMILIES; ++family) {
+        q.ray_slot = family;
         launch_reach(q, stats, s);
         const unsigned rec_blocks = (q.n_refs + 255u) / 256u;
         hipLaunchKernelGGL(rt_park_test_kernel, dim3(rec_blocks < 4096u ? rec_blocks : 4096u), dim3(256), 0, s, q, stats);

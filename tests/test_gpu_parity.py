@@ -614,6 +614,26 @@ def test_zero_direction_rays_parked_and_resumed(rt, orc, parking_renderer, mode,
     test_zero_direction_components_all_patterns(rt, orc, parking_renderer, mode, order)
 
 
+@pytest.mark.parametrize("mirror_walls", [False, True], ids=["one-round", "a-round-per-bounce"])
+@pytest.mark.parametrize("order", ORDERS)
+def test_centre_column_through_the_glass_sphere_parks_whole_families(rt, orc, parking_renderer, order, mirror_walls):
+    """Spheres and mesh together, default camera: the primary rays of the centre pixel column have direction.x == +0 and the glass
+    sphere is centred on x = 0, so the refracted rays stay in the plane x = 0: dozens of bounce rays per frame that the tree
+    cannot prune, all of one family (same origin.x, same zero).  They are parked, resolved together by the whole-chip kernels and
+    resumed.  (From inside, the reference's sphere test only knows the near root, so such a ray leaves its sphere unnoticed and
+    ends on a diffuse wall: one round.)  With perfectly smooth walls -- floor, ceiling and back wall are spheres centred on x = 0
+    too -- the whole column keeps bouncing inside the plane: every resumed path parks again, a round per bounce."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(28))
+    if mirror_walls:
+        scene.materials["roughness"][0] = np.float32(0.0)
+        osc.set_materials(scene.materials)
+    got, want = run_both(rt, orc, parking_renderer, scene, osc, 96, 160, 2, 8, 3, order=order)
+    assert_exact(got, want)
+    col = want["ids"].reshape(160, 96)[:, 48]
+    assert (col == 7).sum() > 20                           # the centre column sees the glass sphere (index 7)
+
+
 @pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("mode", [0, 2])
 def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
