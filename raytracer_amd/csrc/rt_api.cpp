@@ -105,6 +105,7 @@ struct rt_ctx {
     int n_cus = 0;
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
     float root_center[3] = {0.0f, 0.0f, 0.0f}, root_reach = 0.0f;    // see RtParams
+    bool park_min_forced = false;
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
@@ -261,7 +262,7 @@ rt_ctx* rt_create(int device_id)
         rt_destroy(c); return nullptr;
     }
     c->n_cus = prop.multiProcessorCount;
-    if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) c->park_min_nodes = (uint32_t)v; }
+    if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) { c->park_min_nodes = (uint32_t)v; c->park_min_forced = true; } }
     return c;
 }
 
@@ -674,7 +675,11 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     p.fuse_resolve = fused ? 1u : 0u;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
-    const bool parking = mode != RT_SCENE_SPHERES && c->n_nodes >= c->park_min_nodes;
+    // With spheres and mesh together such rays are systematic (the centre column behind a sphere on the camera's x), so they are
+    // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
+    // the rare walk by a wave, except in large trees.
+    if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
+    const bool parking = mode != RT_SCENE_SPHERES && c->n_nodes >= p.park_min_nodes;
     if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));

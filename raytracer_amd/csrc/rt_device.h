@@ -15,6 +15,7 @@
 #define RT_PARK_CHUNK 1024         // ... of which this many wait in LDS at a time while the records stream past
 #define RT_PARK_FAMILIES 2         // ... grouped by (origin.x, sign of the zero): rays of a family visit the same nodes
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
+#define RT_PARK_MIN_NODES_MIXED (1u << 12)   // ... and with spheres and mesh together, where such rays come by the hundred
 #define RT_PARK_WORDS 6            // float4 per parked path
 #define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
 #ifndef RT_NEAR_TIES

@@ -1,9 +1,11 @@
-"""Probe: host time per Render call against GPU time (python tools/host_probe.py <config>)."""
+"""Probe: host time per Render call against GPU time (python tools/host_probe.py <config> [scene mode])."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt, bench
 cfgno = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-cfg = bench.CONFIGS[cfgno]; scene = bench.build_scene(cfg); w, h = cfg["w"], cfg["h"]
+cfg = dict(bench.CONFIGS[cfgno])
+if len(sys.argv) > 2: cfg["mode"] = int(sys.argv[2])
+scene = bench.build_scene(cfg); w, h = cfg["w"], cfg["h"]
 cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
 r = rt.Renderer(0); r.download = False
 st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
