@@ -12,8 +12,9 @@ for cfg in (1, 2, 3, 4, 5):
     summ = os.path.join(root, "gpurun_out", "prof_cfg%d_summary.json" % cfg)
     if not os.path.exists(summ):
         continue
-    for f in glob.glob(d + "/trace/**/*_kernel_stats.csv", recursive=True):
-        shutil.copy(f, os.path.join(root, "profiles", "%s_cfg%d_kernel_stats.csv" % (tag, cfg)))
+    stats = sorted(glob.glob(d + "/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
+    if stats:                                            # the newest: gpurun merges every run's files into the same directory
+        shutil.copy(stats[-1], os.path.join(root, "profiles", "%s_cfg%d_kernel_stats.csv" % (tag, cfg)))
     shutil.copy(summ, os.path.join(root, "profiles", "%s_cfg%d_pmc_summary.json" % (tag, cfg)))
     b = os.path.join(root, "gpurun_out", "bench_cfg%d.json" % cfg)
     if os.path.exists(b):
