@@ -38,6 +38,19 @@
 #ifndef RT_COOP_LANES
 #define RT_COOP_LANES 2            /* a wave with at most this many walks left lends all its lanes to one walk at a time */
 #endif
+/* Tree kernels, end of a frame: a wave that has run out of work adopts paths from the other waves of its workgroup (through a
+   pool in LDS) and, holding at most RT_COOP_LANES of them, walks the tree for them with all its lanes. */
+#ifndef RT_SHARE
+#define RT_SHARE 1                 /* 0 compiles the hand-over out (A/B measurements) */
+#endif
+#ifndef RT_ADOPT
+#define RT_ADOPT 2                 /* paths a wave without work takes from the pool at a time */
+#endif
+#ifndef RT_KEEP
+#define RT_KEEP 2                  /* paths a wave keeps for itself when it gives others away */
+#endif
+#define RT_POOL_SLOTS 16           // paths the pool holds while they change waves
+#define RT_POOL_WORDS 41           // 32-bit words of one path's state
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
 #define RT_WAVE_CLOCK_WORDS 6
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own

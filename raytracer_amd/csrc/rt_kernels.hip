@@ -1288,12 +1288,52 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
 constexpr uint32_t PH_IDLE = 0u, PH_BEGIN = 1u, PH_WALK = 2u, PH_SHADE = 3u, PH_REDO = 4u;
 constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;
 
+// Paths changing waves at the end of a frame.  Every unit is drawn within the first tenth of a tree frame; from then on a
+// wave just finishes the paths it holds and lasts as long as the longest of them, one lane walking while 63 wait, and more
+// and more waves have nothing left at all.  A wave without work therefore takes paths over from the waves of its workgroup
+// that still hold several: the whole per-lane state goes through this pool in LDS.  With at most RT_COOP_LANES paths the
+// adopting wave walks the tree with all 64 lanes for one ray at a time (walk_cooperative), several times faster than the
+// one-lane walk, so the long paths that decide when the frame ends are shortened.  A path is the same sequence of
+// operations whichever lane runs it: results do not change.
+// lock: one wave at a time changes the pool; count: paths waiting in it; hungry: waves waiting for paths;
+// busy: waves that hold paths or may still draw units.  A wave ends when the pool is empty and no wave is busy.
+struct PathPool {
+    uint32_t lock, count, hungry, busy;
+    uint32_t words[RT_POOL_WORDS][RT_POOL_SLOTS];
+};
+
+__device__ __forceinline__ uint32_t pool_peek(uint32_t* word)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void pool_lock(PathPool& pool, uint32_t lane)
+{
+    if (lane == 0) {
+        while (atomicCAS(&pool.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void pool_unlock(PathPool& pool, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(&pool.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int MODE, bool STATS, bool ORDERED>
 __device__ __forceinline__ void tree_body(const RtParams& p)
 {
     __shared__ SceneLds lds;                                // not used: tree scenes read the closest-hit tables from HBM
+    __shared__ PathPool pool;
+    // the counting kernels keep every path in the lane that started it (their per-wave clocks and trip counts describe the plain walk)
+    constexpr bool SHARE = RT_SHARE != 0 && !STATS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (SHARE) {
+        if (threadIdx.x == 0) { pool.lock = 0u; pool.count = 0u; pool.hungry = 0u; pool.busy = blockDim.x >> 6; }
+        __syncthreads();
+    }
+    const bool sharing = SHARE && p.resume == 0u;           // a resume launch only finishes the parked paths
+    bool waiting = false;                                   // wave-uniform: this wave is counted in pool.hungry, not in pool.busy
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
     unsigned long long clock_start = 0, trips = 0, lane_trips = 0, walk_ticks = 0; uint32_t n_iterations = 0;
@@ -1314,8 +1354,29 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     float wtol = 0.0f, wprune = FLT_MAX;
     bool wflag = false;
     F3 winvD = f3(0.0f, 0.0f, 0.0f);
-    const float4* wnodes = p.nodes;
+    uint32_t woct = 0;                                      // which of the eight node arrays the walk reads (0 = the reference's preorder)
     const uint32_t end = p.n_nodes;
+
+    // the whole state of this lane's path to / from slot `slot` of the pool
+    auto path_transfer = [&](const bool save, const uint32_t slot) {
+        uint32_t i = 0;
+        auto U = [&](uint32_t& v) { if (save) pool.words[i][slot] = v; else v = pool.words[i][slot]; ++i; };
+        auto F = [&](float& v) { if (save) pool.words[i][slot] = __float_as_uint(v); else v = __uint_as_float(pool.words[i][slot]); ++i; };
+        uint32_t rng_lo = (uint32_t)s.rng, rng_hi = (uint32_t)(s.rng >> 32), sphere = (uint32_t)iS, tri = (uint32_t)th.id, flag = wflag ? 1u : 0u;
+        U(phase); U(pixel); U(frame); U(path_steps);
+        F(acc.x); F(acc.y); F(acc.z);
+        F(s.O.x); F(s.O.y); F(s.O.z); F(s.D.x); F(s.D.y); F(s.D.z);
+        F(s.contribution.x); F(s.contribution.y); F(s.contribution.z); F(s.finalColor.x); F(s.finalColor.y); F(s.finalColor.z);
+        U(rng_lo); U(rng_hi); U(s.bounce); U(s.column_slot);
+        F(tS); U(sphere); F(th.t); U(tri); F(th.u); F(th.v);
+        U(wnode); U(wrec); U(wbest); U(wsteps); F(wtol); F(wprune); U(flag);
+        F(winvD.x); F(winvD.y); F(winvD.z); U(woct);
+        static_assert(RT_POOL_WORDS == 41, "path_transfer moves 41 words");
+        if (!save) {
+            s.rng = ((unsigned long long)rng_hi << 32) | (unsigned long long)rng_lo;
+            iS = (int)sphere; th.id = (int32_t)tri; wflag = flag != 0u;
+        }
+    };
 
     bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
     uint32_t resume_slot = 0;
@@ -1359,6 +1420,58 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             if (got < want) { heads_empty++; head = (head + 1u) % RT_WORK_HEADS; }
             need = __ballot(phase == PH_IDLE);              // what is still idle: lanes without a unit, and pixels outside the frame
             want = (uint32_t)__popcll(need) / RT_UNIT;
+        }
+        // ---- no units left: paths move from the waves that hold several to the waves that hold none (see PathPool)
+        if (sharing && heads_empty >= RT_WORK_HEADS) {
+            const uint32_t n_live = (uint32_t)__popcll(__ballot(phase != PH_IDLE));
+            if (n_live == 0u) {
+                if (!waiting) {
+                    pool_lock(pool, lane);
+                    if (lane == 0) { pool.busy -= 1u; pool.hungry += 1u; }
+                    pool_unlock(pool, lane);
+                    waiting = true;
+                }
+                bool leave = false;
+                for (;;) {
+                    if (pool_peek(&pool.count) != 0u) {
+                        pool_lock(pool, lane);
+                        const uint32_t have = pool.count;
+                        const uint32_t take = have < (uint32_t)RT_ADOPT ? have : (uint32_t)RT_ADOPT;
+                        if (lane < take) path_transfer(false, have - take + lane);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        if (take != 0u && lane == 0) { pool.count = have - take; pool.hungry -= 1u; pool.busy += 1u; }
+                        pool_unlock(pool, lane);
+                        if (take != 0u) { waiting = false; break; }
+                    } else if (pool_peek(&pool.busy) == 0u) {
+                        pool_lock(pool, lane);
+                        leave = pool.count == 0u && pool.busy == 0u;
+                        pool_unlock(pool, lane);
+                        if (leave) break;
+                    } else __builtin_amdgcn_s_sleep(8);
+                }
+                if (leave) break;
+            } else if (n_live > (uint32_t)RT_KEEP) {
+                const uint32_t wanted = pool_peek(&pool.hungry) * (uint32_t)RT_ADOPT, have = pool_peek(&pool.count);
+                if (wanted > have) {
+                    // the longest walks first: they decide when the frame ends, and the adopting wave walks several times faster
+                    uint32_t give = wanted - have;
+                    if (give > n_live - (uint32_t)RT_KEEP) give = n_live - (uint32_t)RT_KEEP;
+                    const uint32_t rank_class = phase == PH_IDLE ? 4u : (phase != PH_WALK ? 3u : (wsteps >= 64u ? 0u : (wsteps >= 16u ? 1u : 2u)));
+                    uint32_t before = 0, my_rank = 0;
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const unsigned long long m = __ballot(rank_class == k);
+                        if (rank_class == k) my_rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        before += (uint32_t)__popcll(m);
+                    }
+                    pool_lock(pool, lane);
+                    const uint32_t at = pool.count;
+                    if (give > RT_POOL_SLOTS - at) give = RT_POOL_SLOTS - at;
+                    if (phase != PH_IDLE && my_rank < give) { path_transfer(true, at + my_rank); phase = PH_IDLE; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (lane == 0) pool.count = at + give;
+                    pool_unlock(pool, lane);
+                }
+            }
         }
         if (__ballot(phase != PH_IDLE) == 0ull) break;      // nothing in flight and nothing left to take
         n_iterations++;
@@ -1438,11 +1551,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 if (have_hit || end == 0u) phase = PH_SHADE;
                 else {
                     winvD = f3(1.0f / s.D.x, 1.0f / s.D.y, 1.0f / s.D.z);          // Renderer.cpp:151
-                    wnodes = p.nodes;
-                    if (ORDERED) {
-                        const uint32_t octant = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
-                        wnodes += (size_t)octant * 2u * (size_t)p.n_nodes;
-                    }
+                    woct = 0;
+                    if (ORDERED) woct = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
                     wprune = FLT_MAX; wflag = false;
                     if (ORDERED && RT_NEAR_TIES) {
@@ -1499,8 +1609,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         h.t = __shfl(th.t, src); h.id = __shfl(th.id, src); h.u = __shfl(th.u, src); h.v = __shfl(th.v, src);
                         uint32_t best = __shfl(wbest, src);
                         const uint32_t first = __shfl(wnode, src);
-                        const uint32_t lo = __shfl((uint32_t)(uintptr_t)wnodes, src), hi = __shfl((uint32_t)((uintptr_t)wnodes >> 32), src);
-                        const float4* nodes = (const float4*)(((uintptr_t)hi << 32) | (uintptr_t)lo);
+                        const float4* nodes = p.nodes + 2 * ((size_t)__shfl(woct, src) * (size_t)p.n_nodes);
                         const float tol = ORDERED ? __shfl(wtol, src) : 0.0f;
                         const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, h, best);
                         if ((int)lane == src) {
@@ -1519,7 +1628,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     // up to three node steps or two record steps are made from it, which shortens the chain of dependent
                     // loads that a long walk is.
                     const bool at_node = wrec == RT_NO_REC;
-                    const float4* a = at_node ? wnodes + 2 * (size_t)wnode : p.leafrecs + 3 * (size_t)wrec;
+                    // (the cursor is an index into arrays named by the kernel arguments, so these are global loads, not generic ones)
+                    const float4* a = at_node ? p.nodes + 2 * ((size_t)woct * (size_t)p.n_nodes + wnode) : p.leafrecs + 3 * (size_t)wrec;
                     const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5];
                     static_assert(RT_WALK_FETCH == 6, "the walk reads six float4 per trip");
                     // returns true when the walk went down to the next node in memory
