@@ -702,7 +702,7 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
             HIP_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
             q.resume = last ? 2u : 1u;
             const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
-            HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + 255u) / 256u, c->stream));
+            HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
             if (last) break;
             cur = 1 - cur;
             HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));

@@ -10,7 +10,15 @@
 #define RT_MODE_BOTH    2
 
 #define RT_UNIT 16                 // pixels per work unit: an 8x2 strip of an 8x8 tile
+#ifndef RT_TREE_BLOCK
+#define RT_TREE_BLOCK 1024         /* threads per workgroup of the tree-scene trace kernels (its waves share the path pool in LDS) */
+#endif
 #define RT_SPHERE_BLOCK 1024       // threads per workgroup of the sphere-scene trace kernel (16 waves sharing one unit counter in LDS)
+#ifndef RT_SPHERE_MERGE
+#define RT_SPHERE_MERGE 48         /* sphere kernel, end of a share: a wave with at most this many paths hands them to another wave (0 = off) */
+#endif
+#define RT_SPHERE_POOL_SLOTS 128   // paths waiting for another wave (at most 63 + RT_SPHERE_MERGE at a time)
+#define RT_SPHERE_POOL_WORDS 20    // 32-bit words of a sphere-scene path
 #define RT_PARK_SLOTS 4096         // bounce rays the tree cannot prune that one round can hand to whole-chip kernels
 #define RT_PARK_CHUNK 1024         // ... of which this many wait in LDS at a time while the records stream past
 #define RT_PARK_FAMILIES 2         // ... grouped by (origin.x, sign of the zero): rays of a family visit the same nodes

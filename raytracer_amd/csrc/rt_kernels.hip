@@ -593,6 +593,33 @@ struct SceneLds {
     float4 materials[3 * RT_LDS_MATERIALS];
 };
 
+// A lock in LDS taken by one wave at a time (lane 0 spins, the wave follows), and a look at a word other waves change.
+__device__ __forceinline__ uint32_t lds_peek(uint32_t* word)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_lock(uint32_t* lock, uint32_t lane)
+{
+    if (lane == 0) {
+        while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void lds_unlock(uint32_t* lock, uint32_t lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Sphere frames, end of a workgroup's share: every wave still holds paths, but fewer each bounce, and an iteration costs a
+// wave the same whether 60 lanes or 6 are in use.  A wave down to RT_SPHERE_MERGE paths hands them to the pool and ends; the
+// next wave that comes by with idle lanes takes them.  Half as many waves then make the same bounces.
+// count: paths waiting; alive: waves of the workgroup still in the loop (the last one never hands its paths over).
+struct SpherePool {
+    uint32_t lock, count, alive, pad;
+    uint32_t words[RT_SPHERE_POOL_WORDS][RT_SPHERE_POOL_SLOTS];
+};
+
 // All threads of the workgroup call this once before tracing (the host picks the LDS variant only for scenes that fit).
 __device__ __forceinline__ void stage_scene(const RtParams& p, SceneLds& lds)
 {
@@ -1173,9 +1200,11 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
 {
     __shared__ SceneLds lds;                                // only allocated where LDS_SCENE variants use it
     __shared__ uint32_t wg_next;                            // how many of this workgroup's units have been handed out
+    __shared__ SpherePool pool;
+    constexpr bool MERGE = RT_SPHERE_MERGE != 0 && !STATS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (threadIdx.x == 0) wg_next = 0u;
+    if (threadIdx.x == 0) { wg_next = 0u; pool.lock = 0u; pool.count = 0u; pool.alive = blockDim.x >> 6; }
     if (LDS_SCENE) stage_scene(p, lds);
     __syncthreads();
     // wave-uniform: current unit of the workgroup's share and its first free pixel (RT_UNIT = used up)
@@ -1191,6 +1220,20 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
+
+    // this lane's path to / from slot `slot` of the pool
+    auto path_transfer = [&](const bool save, const uint32_t slot) {
+        uint32_t i = 0;
+        auto U = [&](uint32_t& v) { if (save) pool.words[i][slot] = v; else v = pool.words[i][slot]; ++i; };
+        auto F = [&](float& v) { if (save) pool.words[i][slot] = __float_as_uint(v); else v = __uint_as_float(pool.words[i][slot]); ++i; };
+        uint32_t rng_lo = (uint32_t)s.rng, rng_hi = (uint32_t)(s.rng >> 32);
+        U(pixel); U(frame); F(acc.x); F(acc.y); F(acc.z);
+        F(s.O.x); F(s.O.y); F(s.O.z); F(s.D.x); F(s.D.y); F(s.D.z);
+        F(s.contribution.x); F(s.contribution.y); F(s.contribution.z); F(s.finalColor.x); F(s.finalColor.y); F(s.finalColor.z);
+        U(rng_lo); U(rng_hi); U(s.bounce);
+        static_assert(RT_SPHERE_POOL_WORDS == 20, "path_transfer moves 20 words");
+        if (!save) s.rng = ((unsigned long long)rng_hi << 32) | (unsigned long long)rng_lo;
+    };
 
     for (;;) {
         // ---- give idle lanes pixels while there are units left
@@ -1217,7 +1260,47 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
             slot += wanted < avail ? wanted : avail;
             need = __ballot(!live);                         // lanes beyond this unit, and lanes whose pixel fell outside the frame
         }
-        if (__ballot(live) == 0ull) break;                  // nothing in flight and nothing left to take
+        // ---- the share is handed out: waves with few paths left merge them (see SpherePool)
+        if (MERGE && share_done) {
+            const unsigned long long live_mask = __ballot(live);
+            const uint32_t n_live = (uint32_t)__popcll(live_mask);
+            const bool can_take = n_live < 64u && lds_peek(&pool.count) != 0u;
+            const bool may_leave = n_live != 0u && n_live <= (uint32_t)RT_SPHERE_MERGE && lds_peek(&pool.alive) > 1u;
+            if (can_take || may_leave || n_live == 0u) {
+                bool leave = false;
+                lds_lock(&pool.lock, lane);
+                const uint32_t have = pool.count;
+                if (have != 0u) {
+                    // this wave's paths join the waiting ones, and the wave takes up to 64 of them back: every lane is loaded
+                    // anew (lanes beyond `take` read slot 0 and stay idle), so no lane keeps old and new state side by side
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live_mask, 0u));
+                    if (live) path_transfer(true, have + rank);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const uint32_t total = have + n_live;
+                    const uint32_t take = total < 64u ? total : 64u;
+                    path_transfer(false, lane < take ? total - take + lane : 0u);
+                    live = lane < take;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (lane == 0) pool.count = total - take;
+                } else if (n_live == 0u) {
+                    if (lane == 0) pool.alive -= 1u;        // nothing waiting, nothing held: this wave is done
+                    leave = true;
+                } else if (may_leave && pool.alive > 1u) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(live_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live_mask, 0u));
+                    if (live) path_transfer(true, rank);
+                    live = false;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (lane == 0) { pool.count = n_live; pool.alive -= 1u; }
+                    leave = true;                           // another wave of the workgroup is still in the loop and will take them
+                }
+                lds_unlock(&pool.lock, lane);
+                if (leave) break;
+            }
+        }
+        if (__ballot(live) == 0ull) {
+            if (!MERGE) break;                              // nothing in flight and nothing left to take
+            continue;                                       // (merging: the block above decides when an empty wave may end)
+        }
         n_iterations++;
         // The two workgroups of a CU own equal shares, but instruction issue favours the older wave, so one of them would
         // finish at half time and leave the other with half the waves per SIMD.  Issue priority alternates between the
@@ -1301,23 +1384,6 @@ struct PathPool {
     uint32_t lock, count, hungry, busy;
     uint32_t words[RT_POOL_WORDS][RT_POOL_SLOTS];
 };
-
-__device__ __forceinline__ uint32_t pool_peek(uint32_t* word)
-{
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-__device__ __forceinline__ void pool_lock(PathPool& pool, uint32_t lane)
-{
-    if (lane == 0) {
-        while (atomicCAS(&pool.lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(1);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void pool_unlock(PathPool& pool, uint32_t lane)
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(&pool.lock, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 template <int MODE, bool STATS, bool ORDERED>
 __device__ __forceinline__ void tree_body(const RtParams& p)
@@ -1426,50 +1492,50 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             const uint32_t n_live = (uint32_t)__popcll(__ballot(phase != PH_IDLE));
             if (n_live == 0u) {
                 if (!waiting) {
-                    pool_lock(pool, lane);
+                    lds_lock(&pool.lock, lane);
                     if (lane == 0) { pool.busy -= 1u; pool.hungry += 1u; }
-                    pool_unlock(pool, lane);
+                    lds_unlock(&pool.lock, lane);
                     waiting = true;
                 }
                 bool leave = false;
                 for (;;) {
-                    if (pool_peek(&pool.count) != 0u) {
-                        pool_lock(pool, lane);
+                    if (lds_peek(&pool.count) != 0u) {
+                        lds_lock(&pool.lock, lane);
                         const uint32_t have = pool.count;
                         const uint32_t take = have < (uint32_t)RT_ADOPT ? have : (uint32_t)RT_ADOPT;
                         if (lane < take) path_transfer(false, have - take + lane);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                         if (take != 0u && lane == 0) { pool.count = have - take; pool.hungry -= 1u; pool.busy += 1u; }
-                        pool_unlock(pool, lane);
+                        lds_unlock(&pool.lock, lane);
                         if (take != 0u) { waiting = false; break; }
-                    } else if (pool_peek(&pool.busy) == 0u) {
-                        pool_lock(pool, lane);
+                    } else if (lds_peek(&pool.busy) == 0u) {
+                        lds_lock(&pool.lock, lane);
                         leave = pool.count == 0u && pool.busy == 0u;
-                        pool_unlock(pool, lane);
+                        lds_unlock(&pool.lock, lane);
                         if (leave) break;
                     } else __builtin_amdgcn_s_sleep(8);
                 }
                 if (leave) break;
             } else if (n_live > (uint32_t)RT_KEEP) {
-                const uint32_t wanted = pool_peek(&pool.hungry) * (uint32_t)RT_ADOPT, have = pool_peek(&pool.count);
+                const uint32_t wanted = lds_peek(&pool.hungry) * (uint32_t)RT_ADOPT, have = lds_peek(&pool.count);
                 if (wanted > have) {
                     // the longest walks first: they decide when the frame ends, and the adopting wave walks several times faster
                     uint32_t give = wanted - have;
                     if (give > n_live - (uint32_t)RT_KEEP) give = n_live - (uint32_t)RT_KEEP;
-                    const uint32_t rank_class = phase == PH_IDLE ? 4u : (phase != PH_WALK ? 3u : (wsteps >= 64u ? 0u : (wsteps >= 16u ? 1u : 2u)));
+                    const uint32_t rank_class = phase == PH_IDLE ? 4u : (phase == PH_REDO ? 0u : (phase != PH_WALK ? 3u : (wsteps >= 64u ? 0u : (wsteps >= 16u ? 1u : 2u))));
                     uint32_t before = 0, my_rank = 0;
                     for (uint32_t k = 0; k < 4u; ++k) {
                         const unsigned long long m = __ballot(rank_class == k);
                         if (rank_class == k) my_rank = before + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                         before += (uint32_t)__popcll(m);
                     }
-                    pool_lock(pool, lane);
+                    lds_lock(&pool.lock, lane);
                     const uint32_t at = pool.count;
                     if (give > RT_POOL_SLOTS - at) give = RT_POOL_SLOTS - at;
                     if (phase != PH_IDLE && my_rank < give) { path_transfer(true, at + my_rank); phase = PH_IDLE; }
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     if (lane == 0) pool.count = at + give;
-                    pool_unlock(pool, lane);
+                    lds_unlock(&pool.lock, lane);
                 }
             }
         }
@@ -1732,13 +1798,13 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
 // per CU (above 80 it silently admits fewer than the occupancy query promises, and the surplus workgroups of a persistent grid
 // only start when others have finished).
 template <bool STATS, bool LDS_SCENE>
-__global__ __launch_bounds__(RT_SPHERE_BLOCK) __attribute__((amdgpu_num_sgpr(80))) void rt_trace_spheres_kernel(RtParams p)
+__global__ __launch_bounds__(RT_SPHERE_BLOCK) __attribute__((amdgpu_num_sgpr(80), amdgpu_waves_per_eu(8, 8))) void rt_trace_spheres_kernel(RtParams p)
 {
     sphere_body<STATS, LDS_SCENE>(p);
 }
 
 template <int MODE, bool STATS, bool ORDERED>
-__global__ __launch_bounds__(256) void rt_trace_kernel(RtParams p)
+__global__ __launch_bounds__(RT_TREE_BLOCK) void rt_trace_kernel(RtParams p)
 {
     // tree scenes keep the closest-hit lookups in HBM: these kernels are bound by registers (waves per SIMD), not by those loads
     tree_body<MODE, STATS, ORDERED>(p);
@@ -1812,7 +1878,7 @@ static hipError_t for_variant(int mode, int stats, int ordered, int small_scene,
 
 // Resident workgroups per CU of the trace kernel variant: sizes the persistent grid.
 // Threads per workgroup of the variant.
-extern "C" unsigned rt_trace_block(int mode) { return mode == RT_MODE_SPHERES ? RT_SPHERE_BLOCK : 256u; }
+extern "C" unsigned rt_trace_block(int mode) { return mode == RT_MODE_SPHERES ? RT_SPHERE_BLOCK : (unsigned)RT_TREE_BLOCK; }
 
 extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* blocks_per_cu)
 {
