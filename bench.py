@@ -267,7 +267,7 @@ def main():
                        "rays_per_frame": rays_total / (K if tile_split else K * world), "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:             # the CPU oracle is timed beside the one-GPU run only
             n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work
             if cfg["mesh"] and cfg["mesh"][1] > 1000:
                 n = 1                                                    # 10 M triangles at 4K: one frame of every 64th row

@@ -209,6 +209,7 @@ __device__ __forceinline__ F3 camera_dir(const RtParams& p, uint32_t x, uint32_t
 }
 
 struct Hit { float t; int32_t id; float u, v; };
+constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;           // "no leaf record": a walk's cursor is at a node
 
 // ---- spheres: Renderer.cpp:243-271 ------------------------------------------------------------------------------
 // The reference computes t = (-b - sqrt(disc)) / (2a) for every sphere with disc >= 0 and keeps the first strictly smaller
@@ -440,23 +441,41 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
         // so for it "up to and including" is "before"
         const uint32_t pm = wave_prefix_max((valid && !descend) ? skip : 0u);
         const uint32_t limit = pm > killed_to ? pm : killed_to;
-        if (j >= limit && descend && leaf_first >= 0) {
-            uint32_t rec_index = (uint32_t)leaf_first;
-            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
-            float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            for (;;) {
-                const float4 q0 = rec[3], q1 = rec[4], q2 = rec[5];         // the next record (or padding) is in flight during the test
-                rec += 3;
+        // The reached leaves of a window are few (a ray crosses one to three of 64 consecutive nodes) and hold about ten records
+        // each: tested by their own lanes they would be ten triangle tests one after the other with sixty lanes idle.  Instead
+        // up to four leaves are taken per pass, sixteen lanes each, one record per lane (a leaf's records are consecutive, so
+        // a group's read is one run of memory); the record with the end mark closes its group, lanes behind it do not count.
+        // Which lane tests a record does not matter: every lane keeps its own closest hit, merged by (t, record) at the end.
+        unsigned long long leaves = __ballot(j >= limit && descend && leaf_first >= 0);
+        while (leaves != 0ull) {
+            uint32_t group_first = RT_NO_REC;
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) {
+                if (leaves != 0ull) {
+                    const int src = __ffsll((long long)leaves) - 1;
+                    leaves &= leaves - 1ull;
+                    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(leaf_first, src);
+                    if ((lane >> 4) == g) group_first = first;
+                }
+            }
+            bool open = group_first != RT_NO_REC;
+            uint32_t rec_index = group_first + (lane & 15u);
+            while (__ballot(open) != 0ull) {
+                const uint32_t at = rec_index < p.n_refs ? rec_index : p.n_refs - 1u;
+                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+                if (open) { const float4* rec = p.leafrecs + 3 * (size_t)at; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; }
                 const uint32_t tag = __float_as_uint(r2.y);
+                const unsigned long long ends = __ballot(open && (tag & 0x80000000u) != 0u);
+                const uint32_t group_ends = (uint32_t)(ends >> (lane & 48u)) & 0xFFFFu;
+                const bool counts = open && rec_index < p.n_refs && (group_ends & ((1u << (lane & 15u)) - 1u)) == 0u;
                 float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+                if (tri_test(r0, r1, r2, O, D, tt, u, v) && counts) {
                     const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
                     if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + RT_TIE_REL * fminf(tt, t)) near_tie = true;
                     if (tt < t || (tt == t && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
                 }
-                ++rec_index;
-                if (tag & 0x80000000u) break;
-                r0 = q0; r1 = q1; r2 = q2;
+                if (group_ends != 0u) open = false;
+                rec_index += 16u;
             }
         }
         const uint32_t window_kill = (uint32_t)__builtin_amdgcn_readlane((int)pm, 63);
@@ -1369,7 +1388,6 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
 // pruning rule are unchanged, so once a hit is known almost everything behind it is pruned.  Equal t is resolved to the
 // smaller leaf-record index, i.e. to the triangle the reference order reaches first.
 constexpr uint32_t PH_IDLE = 0u, PH_BEGIN = 1u, PH_WALK = 2u, PH_SHADE = 3u, PH_REDO = 4u;
-constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;
 
 // Paths changing waves at the end of a frame.  Every unit is drawn within the first tenth of a tree frame; from then on a
 // wave just finishes the paths it holds and lasts as long as the longest of them, one lane walking while 63 wait, and more
