@@ -98,6 +98,7 @@ struct rt_ctx {
     DevBuf<unsigned long long> d_park_best;
     DevBuf<unsigned long long> d_column_best;
     DevBuf<unsigned char> d_reached;
+    DevBuf<uint32_t> d_rec_leaf;                        // per leaf record: the node index of its leaf (4 bytes instead of the record's 48)
     bool columns_dirty = true;
     uint32_t n_columns = 0;              // host copy of the count (read back once per change)
     uint32_t n_refs = 0;
@@ -167,7 +168,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.counters = c->d_counters.ptr; p.wave_clock = c->wave_clock_on ? c->d_wave_clock.ptr : nullptr; p.column_stats = c->d_column_stats.ptr;
     p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
     p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
-    p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr;
+    p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr; p.rec_leaf = c->d_rec_leaf.ptr;
     p.column_dirs = c->d_column_dirs.ptr; p.column_block = c->d_column_block.ptr;
     p.column_box16 = c->d_column_boxes.ptr;
     p.column_box64 = p.column_box16 + (rt_ctx::kColumnCap + 15u) / 16u;
@@ -276,7 +277,7 @@ void rt_destroy(rt_ctx* c)
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release(); c->d_wave_clock.release(); c->d_column_stats.release(); c->d_work_heads.release();
     c->d_park_count.release(); c->d_park_flags.release(); c->d_park_paths.release(); c->d_park_best.release();
     c->d_park_list.release(); c->d_park_info.release();
-    c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release();
+    c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release(); c->d_rec_leaf.release();
     c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
         if (c->ev_start[i]) (void)hipEventDestroy(c->ev_start[i]);
@@ -537,6 +538,12 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
     HIP_TRY(c, c->d_reached.resize(M));
     HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
+    {
+        std::vector<uint32_t> rec_leaf(recs.size() / 3 + 1, 0u);
+        for (size_t r = 0; r < recs.size() / 3; ++r) memcpy(&rec_leaf[r], &recs[3 * r + 2].z, 4);
+        HIP_TRY(c, c->d_rec_leaf.resize(rec_leaf.size()));
+        HIP_TRY(c, hipMemcpy(c->d_rec_leaf.ptr, rec_leaf.data(), rec_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     {
         float reach[3] = {0.0f, 0.0f, 0.0f};
         for (uint32_t n = 0; n < N; ++n)

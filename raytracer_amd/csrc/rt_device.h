@@ -138,6 +138,8 @@ struct RtParams {
     unsigned long long* column_best;         // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
     uint32_t* column_flags;                  // bit 0: the pre-pass result may not be used (a decision depended on t, or the queue overflowed)
     unsigned char* reached;                  // per node: visited by column rays (pre-pass scratch)
+    const uint32_t* rec_leaf;                // per leaf record: node index of its leaf (what leafrecs[3 r + 2].z holds, packed: the kernels that
+                                             // stream over all records look here first and read only the records of visited leaves)
     // Bounce rays with direction.x == 0 in a large tree ("parked" paths): the trace kernel stores the path and frees the lane,
     // whole-chip kernels find the hit (same reach + test as for the column rays, one ray at a time), a one-workgroup launch of
     // the trace kernel (resume != 0) continues the paths.

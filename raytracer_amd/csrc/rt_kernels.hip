@@ -1097,13 +1097,14 @@ __global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p, int stats
         for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r - threadIdx.x < p.n_refs; r += gridDim.x * 256u) {
             bool use = false;
             float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (r < p.n_refs) { r2 = p.leafrecs[3 * (size_t)r + 2]; use = p.reached[__float_as_uint(r2.z)] != 0; }
+            if (r < p.n_refs) use = p.reached[p.rec_leaf[r]] != 0;
             if (stats) {
                 const uint32_t n = (uint32_t)__popcll(__ballot(use));
                 if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * chunk);
             }
             if (!use) continue;
             const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
+            r2 = p.leafrecs[3 * (size_t)r + 2];
             const F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
             for (uint32_t k = 0; k < chunk; ++k) {
                 const float4 o4 = ray_o[k], d4 = ray_d[k];
@@ -1135,9 +1136,8 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
     bool use = false;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     if (r < p.n_refs) {
-        r2 = p.leafrecs[3 * (size_t)r + 2];
-        use = p.reached[__float_as_uint(r2.z)] != 0;
-        if (use) { r0 = p.leafrecs[3 * (size_t)r]; r1 = p.leafrecs[3 * (size_t)r + 1]; }
+        use = p.reached[p.rec_leaf[r]] != 0;
+        if (use) { r0 = p.leafrecs[3 * (size_t)r]; r1 = p.leafrecs[3 * (size_t)r + 1]; r2 = p.leafrecs[3 * (size_t)r + 2]; }
     }
     const unsigned long long any = __ballot(use);
     if (stats) {
