@@ -1322,10 +1322,14 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
         }
         n_iterations++;
         // The two workgroups of a CU own equal shares, but instruction issue favours the older wave, so one of them would
-        // finish at half time and leave the other with half the waves per SIMD.  Issue priority alternates between the
-        // two halves of the grid every iteration, which keeps them abreast.
-        if ((n_iterations ^ (blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
+        // finish at half time and leave the other with half the waves per SIMD.  Issue priority goes to the younger half of
+        // the grid in RT_SPHERE_PRIO of every 8 iterations and to the older half in the rest (measured: with 4 of 8 the older
+        // workgroups still finish 50 us early, with 8 of 8 the younger ones do; 6 of 8 brings them within 15 us).
+        {
+            const bool younger = blockIdx.x >= (gridDim.x >> 1);
+            const bool favoured = ((n_iterations & 7u) < (uint32_t)RT_SPHERE_PRIO) == younger;
+            if (favoured) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
 
         // ---- one bounce for every lane with a path
         if (live) {
