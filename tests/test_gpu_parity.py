@@ -155,6 +155,37 @@ def test_refraction_and_total_internal_reflection(rt, orc, renderer):
     assert_exact(got, want)
 
 
+@pytest.mark.parametrize("extra,mode", [(40, 1), (150, 1), (150, 2)], ids=["49-spheres", "159-spheres", "159-spheres+mesh"])
+def test_many_spheres_beyond_the_kernel_argument_and_lds_copies(rt, orc, renderer, extra, mode):
+    """The first 32 spheres travel in the kernel arguments and scenes of up to 128 spheres / materials keep them in LDS;
+    larger scenes read both from HBM (other kernel variants).  Default scene + a cloud of small spheres, each with a
+    material of its own (diffuse, mirror-like, glass and emissive ones), bit-exact against the oracle."""
+    from raytracer_amd import scenes
+    rng = np.random.default_rng(7)
+    mesh = None
+    if mode == 2:
+        mesh = scenes.displaced_grid(12, x_range=(-1.2, 1.2), z_range=(-2.4, 0.0), mat_offset=0)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    base = len(scene.materials)
+    sph = np.zeros(extra, dtype=scenes.SPHERE_DTYPE)
+    sph["x"] = rng.uniform(-0.95, 0.95, extra); sph["y"] = rng.uniform(0.05, 1.8, extra); sph["z"] = rng.uniform(-1.9, 0.5, extra)
+    sph["radius"] = rng.uniform(0.03, 0.12, extra); sph["material"] = base + np.arange(extra)
+    mats = []
+    for i in range(extra):
+        kind = i % 4
+        col = tuple(rng.uniform(0.2, 1.0, 3))
+        if kind == 0: mats.append(scenes.make_material(col, roughness=1.0))
+        elif kind == 1: mats.append(scenes.make_material(col, roughness=0.05))
+        elif kind == 2: mats.append(scenes.make_material(col, roughness=0.0, transparency=1.0, ior=1.3))
+        else: mats.append(scenes.make_material(col, emission=tuple(rng.uniform(0.5, 3.0, 3)), roughness=1.0))
+    scene.spheres = np.concatenate([scene.spheres, sph])
+    scene.materials = np.concatenate([scene.materials, np.array(mats, dtype=scenes.MATERIAL_DTYPE)])
+    osc.set_spheres(scene.spheres); osc.set_materials(scene.materials)
+    got, want = run_both(rt, orc, renderer, scene, osc, 160, 100, mode, 6, 3, order=F2B_ORDER if mode == 2 else 0)
+    assert_exact(got, want, ("rays", "sphere_tests"))
+    assert len(np.unique(want["ids"][(want["ids"] >= 9) & (want["ids"] < 0x40000000)])) >= extra // 3     # the cloud is seen
+
+
 def test_device_ray_generation_bit_exact(rt, orc, renderer):
     g = np.load(os.path.join(GOLD, "ref_kat.npz"))
     scene, _ = make_scene(rt, orc)
