@@ -333,9 +333,15 @@ def test_spheres_and_mesh_together(rt, orc, renderer, order):
 
 
 # ---- Renderer semantics ----------------------------------------------------------------------------------------------------
-def test_frames_in_one_launch_equal_separate_launches(rt, orc, renderer):
-    scene, osc = make_scene(rt, orc)
-    got, want = run_both(rt, orc, renderer, scene, osc, 160, 96, 1, 5, 6)
+@pytest.mark.parametrize("mode", [1, 0, 2], ids=["spheres", "mesh", "spheres+mesh"])
+def test_frames_in_one_launch_equal_separate_launches(rt, orc, renderer, mode):
+    """Several frames per launch (a lane keeps its pixel and adds the frames in order) against one launch per frame and the
+    oracle; in the tree modes the paths also change waves on the way (most waves of so small a frame start without work)."""
+    from raytracer_amd import scenes
+    mesh = None if mode == 1 else scenes.displaced_grid(40, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    got, want = run_both(rt, orc, renderer, scene, osc, 160, 96, mode, 5, 6)
+    assert_exact(got, want)
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(160, 96)
     renderer.ResetFrameIndex()
     renderer.Render(scene, cam, frames=4)
