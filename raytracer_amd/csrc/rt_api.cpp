@@ -178,6 +178,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.park_count = c->d_park_count.ptr; p.park_flags = c->d_park_flags.ptr; p.park_paths = c->d_park_paths.ptr; p.park_best = c->d_park_best.ptr;
     p.resume_count = c->d_park_count.ptr; p.resume_paths = c->d_park_paths.ptr; p.park_list = c->d_park_list.ptr; p.park_info = c->d_park_info.ptr;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
+    p.slice_leave = c->n_nodes >= RT_LARGE_TREE ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
     for (int a = 0; a < 3; ++a) p.root_center[a] = c->root_center[a];
     p.root_reach = c->root_reach;
 }

@@ -44,8 +44,13 @@
 #define RT_TIE_REL 1.9073486328125e-6f   /* 2^-19 */
 #endif
 #ifndef RT_SLICE_LEAVE
-#define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left */
+#define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left ... */
 #endif
+#ifndef RT_SLICE_LEAVE_LARGE
+#define RT_SLICE_LEAVE_LARGE 3     /* ... in a tree of at least RT_LARGE_TREE nodes (walks there are long and alike: shorter slices keep
+                                      more lanes walking; measured 10 M triangles -2 %, 70 k triangles +2 %) */
+#endif
+#define RT_LARGE_TREE (1u << 18)
 #ifndef RT_COOP_LANES
 #define RT_COOP_LANES 2            /* a wave with at most this many walks left lends all its lanes to one walk at a time */
 #endif
@@ -155,6 +160,7 @@ struct RtParams {
     uint32_t* park_list;                     // RT_PARK_FAMILIES x RT_PARK_SLOTS: the slots of each family
     int32_t*  park_info;                     // per family: [f] representative slot (-1 = none), [2 + f] size, [4 + f] bit 0: visited set depends on t
     uint32_t  park_min_nodes;                // park only in trees with at least this many nodes
+    uint32_t  slice_leave;                   // a walk slice of the trace kernel ends when this many quarters of its walkers are left
     float     root_center[3];                // centre of the tree's root box and the sum over the axes of the largest
     float     root_reach;                    // |node centre - root centre| + node half-extent: bounds |box plane - point in the tree|
     int32_t   ray_slot;                      // which rays the reach / test kernels serve: -1 = the column rays, else a family of parked rays

@@ -1675,7 +1675,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 }
             }
             unsigned long long walking = __ballot(phase == PH_WALK);
-            const uint32_t leave_at = ((uint32_t)__popcll(walking) * RT_SLICE_LEAVE) >> 2;
+            const uint32_t leave_at = ((uint32_t)__popcll(walking) * p.slice_leave) >> 2;
             // a long walk is a chain of dependent loads: its wave asks for issue priority, so that the few long rays that
             // decide when the frame ends are not queued behind the bulk of short ones
             if (__ballot(phase == PH_WALK && wsteps >= RT_LONG_WALK) != 0ull) __builtin_amdgcn_s_setprio(3);
