@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-# Algorithmic work per ray / per pixel-frame (stated in DESIGN.md):
+# Algorithmic work per ray / per pixel-frame:
 FLOPS_PER_SPHERE_RAY = lambda n_spheres: 6 + 24 * n_spheres + 120   # intersection + closest-hit/shade/scatter/roulette
 FLOPS_PER_PIXEL_RESOLVE = 40
 BYTES_PER_PIXEL_FRAME = 40          # accumulation read 12 + write 12 + RGBA32F write 16
