@@ -20,6 +20,9 @@
 #ifndef RT_SPHERE_PRIO
 #define RT_SPHERE_PRIO 6           /* sphere kernel: iterations of every 8 in which the younger workgroup of a CU has issue priority */
 #endif
+#ifndef RT_SPHERE_PRIO_PERIOD
+#define RT_SPHERE_PRIO_PERIOD 8
+#endif
 #define RT_SPHERE_POOL_SLOTS 128   // paths waiting for another wave (at most 63 + RT_SPHERE_MERGE at a time)
 #define RT_SPHERE_POOL_WORDS 20    // 32-bit words of a sphere-scene path
 #define RT_PARK_SLOTS 4096         // bounce rays the tree cannot prune that one round can hand to whole-chip kernels

@@ -1324,10 +1324,11 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
         // The two workgroups of a CU own equal shares, but instruction issue favours the older wave, so one of them would
         // finish at half time and leave the other with half the waves per SIMD.  Issue priority goes to the younger half of
         // the grid in RT_SPHERE_PRIO of every 8 iterations and to the older half in the rest (measured: with 4 of 8 the older
-        // workgroups still finish 50 us early, with 8 of 8 the younger ones do; 6 of 8 brings them within 15 us).
+        // workgroups still finish 50 us early, with 8 of 8 the younger ones do; 6 of 8 brings them within 15 us;
+        // RT_SPHERE_PRIO_PERIOD, a power of two, is the 8).
         {
             const bool younger = blockIdx.x >= (gridDim.x >> 1);
-            const bool favoured = ((n_iterations & 7u) < (uint32_t)RT_SPHERE_PRIO) == younger;
+            const bool favoured = ((n_iterations & (uint32_t)(RT_SPHERE_PRIO_PERIOD - 1)) < (uint32_t)RT_SPHERE_PRIO) == younger;
             if (favoured) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         }
 
