@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the tracing path: Mrays/s (primary + bounce) and ms/frame.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|3|4|5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|1|3|4|5] [--no-other-configs] [--no-cpu-baseline]
 
-A step is one Renderer::Render (one 1-spp frame) of the configured scene.  Default workload = BASELINE.json configs[1]:
-the reference application's default sphere scene at 1920x1080, 5 bounces, 64 accumulated frames.  With N > 1 (launched
-under torch.distributed.run, one rank per GPU) the frames are sample-split: every rank renders K frames of its own
-frame indices, the accumulation buffers are summed once over RCCL at the end of the timed region and rank 0 resolves the
-image; value = rays traced by all ranks / max-over-ranks time (weak scaling).
+A step is one Renderer::Render (one 1-spp frame, one launch) of the configured scene.  Default workload = BASELINE.json
+configs[1]: the reference application's default sphere scene at 1920x1080, 5 bounces, 64 accumulated frames.  With N > 1
+(launched under torch.distributed.run, one rank per GPU) the frames are sample-split: every rank renders K frames of its own
+frame indices, the accumulation buffers are summed once over RCCL onto rank 0 at the end of the timed region and rank 0 resolves
+the image; value = rays traced by all ranks / max-over-ranks time (weak scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel (device time from HIP events on its launch stream)
-against the bound that applies to the workload; `cpu_baseline` times the CPU oracle on a bounded sample of the same
-workload on this box's host cores.
+Rank 0 prints ONE JSON line.  `roofline` prices the trace kernel (device time from HIP events on its launch stream) against
+the bound that applies to the workload; `cpu_baseline` times the CPU oracle on a bounded sample of the same workload on this
+box's host cores.  Beside the one-Render-per-launch figures the line carries
+  * `throughput_mode`: the same frames as launches of 16 Renders (rt_render_frames), what a progressive accumulation uses;
+  * `with_d2h`: ms per Render including the hand-off of the RGBA32F frame to host memory (rt_map_image, and the pipelined
+    variant that copies frame k beside the trace of frame k + 1) -- what the drop-in Renderer::Render costs;
+  * `other_configs` (one-GPU default run only): the tree configurations 3 and 4, measured the same way in the same process.
 """
 import argparse
 import json
@@ -33,6 +37,8 @@ BYTES_PER_NODE, BYTES_PER_TRI, BYTES_PER_HIT = 32, 40, 40
 # fuse (bit-exact contract), so one operation per lane per issue slot: 256 CU x 128 lanes/clk x 2.4 GHz.
 PEAK_VALU_NOFMA_TFLOPS = 78.6
 PEAK_HBM_GBS = 8000.0
+FRAMES_PER_LAUNCH = 16              # throughput mode (= RT_MAX_LAUNCH_FRAMES of tree scenes)
+ORDERS = {"auto": 0, "reference": 1, "front-to-back": 2}
 
 CONFIGS = {
     1: dict(name="default sphere scene 1280x720, 5 bounces (BASELINE configs[0])", w=1280, h=720, bounces=5, mode=1, mesh=None),
@@ -46,6 +52,30 @@ CONFIGS = {
     5: dict(name="default spheres + 9,999,392-triangle mesh, 3840x2160, 8 bounces, progressive, sample split (BASELINE configs[4])",
             w=3840, h=2160, bounces=8, mode=2, mesh=("grid", 2236, 10.0)),
 }
+
+
+def host_threads():
+    """Threads for host-side work: this process's CPU share (a GPU box shows the whole machine's CPUs to os.cpu_count())."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) >= 1:
+            n = min(n, int(v))
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def build_scene(cfg):
@@ -62,35 +92,209 @@ def build_scene(cfg):
                                                                               mat_offset=len(mats))
         else:
             verts, tris, normals9, tri_mat, mesh_mats = scenes.cube_sphere(n, mat_offset=len(mats))
-        scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=min(16, os.cpu_count() or 1))
+        scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=min(16, host_threads()))
         mats = np.concatenate([mats, mesh_mats])
     scene.materials = mats
     return scene
 
 
 def cpu_baseline(cfg, scene, cam, budget_frames):
-    """Time the oracle (CPU restatement, per-pixel-hash RNG mode) on a bounded sample of the workload."""
+    """Time the oracle (CPU restatement, per-pixel-hash RNG mode) on a bounded sample of the workload: on all host threads of
+    this process's CPU share, and on one thread over a quarter of the sample."""
     from oracle import orc
     w, h = cfg["w"], cfg["h"]
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_threads()
     oscene = orc.Scene()
     oscene.set_spheres(scene.spheres); oscene.set_materials(scene.materials)
-    row_step = 64 if (cfg["mesh"] and cfg["mesh"][1] > 1000) else 1
+    big = bool(cfg["mesh"] and cfg["mesh"][1] > 1000)
+    row_step = 64 if big else 1
     if scene.kd_tree is not None:
         oscene.set_mesh(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat)
         oscene.import_kd(scene.kd_tree.arrays())
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
     st = orc.Settings(1, cfg["mode"], 1, 0, cfg["bounces"])
-    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
-    cnt = orc.Counters()
-    t0 = time.perf_counter()
-    for f in range(1, budget_frames + 1):
-        oscene.render_frame(st, cam.GetPosition(), dirs, w, h, f, acc, img, counters=cnt, nthreads=threads, row_step=row_step)
-    dt = time.perf_counter() - t0
-    return {"value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+
+    def run(nthreads, frames, step):
+        acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+        cnt = orc.Counters()
+        t0 = time.perf_counter()
+        for f in range(1, frames + 1):
+            oscene.render_frame(st, cam.GetPosition(), dirs, w, h, f, acc, img, counters=cnt, nthreads=nthreads, row_step=step)
+        return cnt.rays, time.perf_counter() - t0
+
+    rays, dt = run(threads, budget_frames, row_step)
+    one_step = row_step * (16 if big else 8)                     # the one-thread leg sees an eighth (a sixteenth) of the rows of one frame
+    rays1, dt1 = run(1, 1, one_step)
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
+            "host_cpus_visible": os.cpu_count(),
             "sample": "%d frame(s) of the same %dx%d workload%s, oracle (CPU restatement, hash RNG), %.1f s wall"
                       % (budget_frames, w, h, "" if row_step == 1 else ", every %dth row" % row_step, dt),
-            "ms_per_frame_extrapolated": dt / budget_frames * 1e3 * row_step}
+            "ms_per_frame_extrapolated": dt / budget_frames * 1e3 * row_step,
+            "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                           "sample": "1 frame, every %dth row, %.1f s wall" % (one_step, dt1),
+                           "ms_per_frame_extrapolated": dt1 * 1e3 * one_step}}
+
+
+def _traffic_from_profile(config):
+    """HBM bytes per launch of the trace kernel from the committed PMC pass (profiles/traffic.json), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get("config%d" % config, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+TRAFFIC_SOURCE = "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of a rocprofv3 --pmc pass over this command, committed; not measured in this run"
+
+
+def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world):
+    """Price the trace kernel of the timed launches (cnt / kt: their counters and event times) against its bound."""
+    px = cfg["w"] * cfg["h"]
+    launches = max(kt.launches, 1)
+    avg_kernel_s = kt.total_ms / launches / 1e3
+    rays_per_launch = cnt.rays / launches
+    traffic = _traffic_from_profile(config_id)
+    if cfg["mode"] == 1:
+        flops = rays_per_launch * FLOPS_PER_SPHERE_RAY(len(scene.spheres)) + px * FLOPS_PER_PIXEL_RESOLVE
+        achieved = flops / avg_kernel_s / 1e12
+        return {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE,
+                "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
+                "hbm_moved_GBs": (traffic / avg_kernel_s / 1e9) if traffic else None,
+                "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+                "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
+                "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path; accum and dirs are float4 "
+                        "(32 B + 16 B per pixel against the 24 B + 0 B of the 40 B/pixel model), hence traffic about twice the algorithmic bytes"}
+    # node / triangle counts of the same frames, from an untimed pass with the counting kernel
+    r.set_stats(True); r.reset_accum(); r.reset_counters()
+    for f in frames:
+        r.render_only(f)
+    c2 = r.read_counters()
+    order_used = "front-to-back" if r.traversal_in_use() == 2 else "reference"
+    ref_counts = None
+    if order_used != "reference":                # what the reference's own walk order costs on the same rays
+        st.TraversalOrder = 1; r.push_settings()
+        r.reset_accum(); r.reset_counters()
+        for f in frames[:4]:
+            r.render_only(f)
+        c3 = r.read_counters()
+        ref_counts = {"nodes_per_ray": (c3.nodes_visited - c3.prepass_nodes) / max(c3.rays, 1),
+                      "tris_per_ray": (c3.tris_tested - c3.prepass_tris) / max(c3.rays, 1)}
+        st.TraversalOrder = ORDERS[order_name]; r.push_settings()
+    r.set_stats(False)
+    # grazing ties: primary ids that differ between the reference walk order and front to back (one frame each, untimed)
+    order_ties = None
+    if order_used != "reference" and world == 1:
+        ids = {}
+        for o in (1, 2):
+            st.TraversalOrder = o; r.push_settings(); r.record_ids(True)
+            r.render_only(1); ids[o] = r.read_primary_ids()
+        r.record_ids(False)
+        st.TraversalOrder = ORDERS[order_name]; r.push_settings()
+        order_ties = {"primary_ids_differing_from_reference_order": int((ids[1] != ids[2]).sum()), "pixels": int(px)}
+    per_launch = lambda v: v / max(len(frames), 1)
+    # what the trace kernel itself walked: the counters minus the part that stands for the column rays (primary rays with
+    # direction.x == +0), which the pre-pass resolves without walking the tree ray by ray
+    own_nodes = per_launch(c2.nodes_visited - c2.prepass_nodes)
+    own_tris = per_launch(c2.tris_tested - c2.prepass_tris)
+    bytes_ = (own_nodes * BYTES_PER_NODE + own_tris * BYTES_PER_TRI + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
+    achieved = bytes_ / avg_kernel_s / 1e9
+    small = cfg["mesh"][1] < 1000
+    return {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+            "traffic": traffic, "traffic_source": TRAFFIC_SOURCE,
+            "hbm_moved_GBs": (traffic / avg_kernel_s / 1e9) if traffic else None,
+            "frac_hbm_moved": (traffic / avg_kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None,
+            "algorithmic_bytes_per_launch": bytes_,
+            "kernel": "rt_trace_kernel<%s, %s>" % ("mesh" if cfg["mode"] == 0 else "spheres+mesh", order_used),
+            "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+            "prepass_avg_ms": kt.prepass_total_ms / launches,
+            "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
+            "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
+            "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
+            "grazing_ties": order_ties,
+            "near_tie_rewalks_per_frame": cnt.near_ties / launches,
+            "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
+                    "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
+                    "that was timed; `frac` prices them against the HBM peak as the contract asks, `frac_hbm_moved` is what the PMC "
+                    "counters saw reach HBM; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "
+                    + ("nodes (8 x 3.6 MB) + leaf records (17 MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
+                       else "nodes (8 x 0.5 GB) + leaf records (2.4 GB) are HBM-resident: random 32-48 B reads")}
+
+
+def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=None, n_spheres=9):
+    """The same workload as launches of FRAMES_PER_LAUNCH Renders (rt_render_frames): what a progressive accumulation uses."""
+    r.reset_accum(); r.render_only(1001, FRAMES_PER_LAUNCH)                     # warm: slot planes are allocated here
+    r.sync(); torch.cuda.synchronize()
+    r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
+    t0 = time.perf_counter()
+    for i in range(launches):
+        r.render_only(1 + i * FRAMES_PER_LAUNCH, FRAMES_PER_LAUNCH)
+    r.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cnt, kt = r.read_counters(), r.kernel_time()
+    frames = launches * FRAMES_PER_LAUNCH
+    kernel_ms_per_frame = kt.total_ms / max(kt.frames, 1)
+    out = {"frames_per_launch": FRAMES_PER_LAUNCH, "launches": launches, "ms_per_frame": dt / frames * 1e3,
+           "value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "kernel_ms_per_frame": kernel_ms_per_frame,
+           "prepass_ms_per_frame": kt.prepass_total_ms / max(kt.frames, 1), "rays_per_frame": cnt.rays / frames}
+    if cfg["mode"] == 1:
+        flops = rays_per_frame * FLOPS_PER_SPHERE_RAY(n_spheres) + cfg["w"] * cfg["h"] * FLOPS_PER_PIXEL_RESOLVE
+        out["roofline_frac"] = flops / (kernel_ms_per_frame / 1e3) / 1e12 / PEAK_VALU_NOFMA_TFLOPS
+    elif bytes_per_frame:
+        out["roofline_frac"] = bytes_per_frame / (kernel_ms_per_frame / 1e3) / 1e9 / PEAK_HBM_GBS
+    return out
+
+
+def with_d2h(r, torch, steps):
+    """ms per Render including the frame's way to host memory, as the drop-in Renderer::Render ends (Renderer.cpp:134)."""
+    out = {}
+    for name, pipelined in (("ms_per_step_map_image", False), ("ms_per_step_map_image_pipelined", True)):
+        r.reset_accum()
+        for f in range(1, 4):
+            r.render_only(f); r.map_image(pipelined)
+        r.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for f in range(1, steps + 1):
+            r.render_only(f); r.map_image(pipelined)
+        r.sync(); torch.cuda.synchronize()
+        out[name] = (time.perf_counter() - t0) / steps * 1e3
+    out["note"] = ("rt_render + rt_map_image per step: the RGBA32F frame lands in page-locked host memory of the library; pipelined = the "
+                   "copy of frame k runs beside the trace of frame k + 1 and each call returns the previous frame")
+    return out
+
+
+def run_single(config_id, steps, warmup, order_name, torch, device=0):
+    """One-GPU measurement of a configuration, one Render per launch, plus throughput mode.  Returns (record, scene, cam)."""
+    import raytracer_amd as rt
+    cfg = CONFIGS[config_id]
+    w, h = cfg["w"], cfg["h"]
+    scene = build_scene(cfg)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    r = rt.Renderer(device)
+    r.download = False
+    st = r.GetSettings()
+    st.SceneMode, st.Bounces, st.TraversalOrder = cfg["mode"], cfg["bounces"], ORDERS[order_name]
+    r.OnResize(w, h)
+    r.upload(scene, cam)
+    r.reset_accum()
+    for f in range(1, warmup + 1):
+        r.render_only(f + 1000)
+    r.sync(); torch.cuda.synchronize()
+    r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
+    frames = list(range(1, steps + 1))
+    t0 = time.perf_counter()
+    for f in frames:
+        r.render_only(f)
+    r.sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    cnt, kt = r.read_counters(), r.kernel_time()
+    roof = roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, 1)
+    rec = {"config": config_id, "workload": cfg["name"], "value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "steps": steps,
+           "ms_per_step": dt / steps * 1e3, "rays_per_frame": cnt.rays / steps, "roofline": roof,
+           "throughput_mode": throughput_mode(r, cfg, torch, max(1, steps // FRAMES_PER_LAUNCH), cnt.rays / steps,
+                                              roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))}
+    return rec, scene, cam, r
 
 
 def main():
@@ -100,8 +304,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the tree configurations 3 and 4 of the default one-GPU run")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
-    ap.add_argument("--order", default="auto", choices=["auto", "reference", "front-to-back"],
+    ap.add_argument("--order", default="auto", choices=sorted(ORDERS),
                     help="KD tree walk order of mesh scenes (auto = front to back on a KD tree)")
     args = ap.parse_args()
 
@@ -135,10 +340,10 @@ def main():
     cam = rt.Camera(70.0, 0.05, 100.0)
     cam.OnResize(w, h)
     r = rt.Renderer(local_rank)
-    r.download = False                               # frames stay in HBM; the host copy is priced separately
+    r.download = False                               # frames stay in HBM; the host copy is priced separately (with_d2h)
     st = r.GetSettings()
     st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
-    st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]
+    st.TraversalOrder = ORDERS[args.order]
     r.OnResize(w, h)
     stream = torch.cuda.Stream()                     # one stream for the kernels and the collective that follows them
     torch.cuda.set_stream(stream)
@@ -154,19 +359,20 @@ def main():
         # screen-tile split: every rank renders all K frames of its own 16-row bands; bands are gathered on rank 0 per frame
         r.set_bands(rank, world)
         warm = list(range(1, W + 1)); frames = list(range(1, K + 1))
-        img_t = rtd.image_tensor(r) if use_dist else None
+        bands = rtd.BandGather(rtd.image_tensor(r), rank, world) if use_dist else None
         acc_t = None
     else:
         # sample split: rank r renders frame indices r+1, r+1+N, ... (world == 1: 1, 2, 3, ...)
         warm = rtd.frames_for_rank(rank, world, W)
         frames = rtd.frames_for_rank(rank, world, K, first=1)
         acc_t = rtd.accum_tensor(r) if use_dist else None
+        bands = None
 
     r.reset_accum()
     for f in warm:
         r.render_only(f + 1000)                      # warmup only heats caches/clocks; its sum is discarded
-        if tile_split and use_dist:
-            rtd.gather_bands(img_t, rank, world)
+        if bands is not None:
+            bands.gather()
     if use_dist and not tile_split:
         rtd.sum_accumulation(acc_t)
     r.sync(); torch.cuda.synchronize(); barrier()
@@ -176,10 +382,10 @@ def main():
     t0 = time.perf_counter()
     for f in frames:                                 # every rank starts from a zeroed buffer (rt_reset_accum)
         r.render_only(f)
-        if tile_split and use_dist:
-            rtd.gather_bands(img_t, rank, world)     # the displayed frame, assembled on rank 0
+        if bands is not None:
+            bands.gather()                           # the displayed frame, assembled on rank 0
     if use_dist and not tile_split:
-        rtd.sum_accumulation(acc_t)
+        rtd.sum_accumulation(acc_t)                  # RCCL reduce of the rgb sums onto rank 0
         if rank == 0:
             r.resolve(world * K)
     torch.cuda.synchronize(); barrier()
@@ -195,69 +401,7 @@ def main():
     kt = r.kernel_time()
 
     if rank == 0:
-        px = w * h
-        avg_kernel_s = kt.total_ms / max(kt.launches, 1) / 1e3
-        rays_per_launch = cnt.rays / max(kt.launches, 1)
-        if cfg["mode"] == 1:
-            flops = rays_per_launch * FLOPS_PER_SPHERE_RAY(len(scene.spheres)) + px * FLOPS_PER_PIXEL_RESOLVE
-            achieved = flops / avg_kernel_s / 1e12
-            roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_VALU_NOFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": _traffic_from_profile(args.config),
-                    "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
-                    "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
-                    "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
-                    "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path"}
-        else:
-            # node / triangle counts of the same frames, from an untimed pass with the counting kernel
-            r.set_stats(True); r.reset_accum(); r.reset_counters()
-            for f in frames:
-                r.render_only(f)
-            c2 = r.read_counters()
-            order_used = "front-to-back" if r.traversal_in_use() == 2 else "reference"
-            ref_counts = None
-            if order_used != "reference":                # what the reference's own walk order costs on the same rays
-                st.TraversalOrder = 1; r.push_settings()
-                r.reset_accum(); r.reset_counters()
-                for f in frames[:4]:
-                    r.render_only(f)
-                c3 = r.read_counters()
-                ref_counts = {"nodes_per_ray": (c3.nodes_visited - c3.prepass_nodes) / max(c3.rays, 1),
-                              "tris_per_ray": (c3.tris_tested - c3.prepass_tris) / max(c3.rays, 1)}
-                st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
-            r.set_stats(False)
-            # grazing ties: primary ids that differ between the reference walk order and front to back (one frame each, untimed)
-            order_ties = None
-            if order_used != "reference" and world == 1:
-                ids = {}
-                for o in (1, 2):
-                    st.TraversalOrder = o; r.push_settings(); r.record_ids(True)
-                    r.render_only(1); ids[o] = r.read_primary_ids()
-                r.record_ids(False)
-                st.TraversalOrder = {"auto": 0, "reference": 1, "front-to-back": 2}[args.order]; r.push_settings()
-                order_ties = {"primary_ids_differing_from_reference_order": int((ids[1] != ids[2]).sum()), "pixels": int(px)}
-            per_launch = lambda v: v / max(len(frames), 1)
-            # what the trace kernel itself walked: the counters minus the part that stands for the column rays (primary rays with
-            # direction.x == +0), which the pre-pass resolves without walking the tree ray by ray
-            own_nodes = per_launch(c2.nodes_visited - c2.prepass_nodes)
-            own_tris = per_launch(c2.tris_tested - c2.prepass_tris)
-            bytes_ = (own_nodes * BYTES_PER_NODE + own_tris * BYTES_PER_TRI + rays_per_launch * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
-            achieved = bytes_ / avg_kernel_s / 1e9
-            small = cfg["mesh"][1] < 1000
-            roof = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                    "traffic": _traffic_from_profile(args.config),
-                    "kernel": "rt_trace_kernel<%s, %s>" % ("mesh" if cfg["mode"] == 0 else "spheres+mesh", order_used),
-                    "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
-                    "prepass_avg_ms": kt.prepass_total_ms / max(kt.launches, 1),
-                    "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
-                    "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
-                    "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
-                    "grazing_ties": order_ties,
-                    "near_tie_rewalks_per_frame": cnt.near_ties / max(kt.launches, 1),
-                    "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
-                            "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
-                            "that was timed; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "
-                            + ("nodes (8 x 3.6 MB) + leaf records (17 MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
-                               else "nodes (8 x 0.5 GB) + leaf records (2.4 GB) are HBM-resident: random 32-48 B reads")}
+        roof = roofline(args.config, cfg, scene, r, st, args.order, frames, cnt, kt, world)
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
@@ -267,26 +411,33 @@ def main():
                        "rays_per_frame": rays_total / (K if tile_split else K * world), "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
+        if world == 1 and not use_dist:
+            out["throughput_mode"] = throughput_mode(r, cfg, torch, max(1, K // FRAMES_PER_LAUNCH), rays_total / K,
+                                                     roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))
+            out["with_d2h"] = with_d2h(r, torch, min(K, 32))
         if not args.no_cpu_baseline and world == 1:             # the CPU oracle is timed beside the one-GPU run only
             n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work
             if cfg["mesh"] and cfg["mesh"][1] > 1000:
                 n = 1                                                    # 10 M triangles at 4K: one frame of every 64th row
             out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
+        if world == 1 and not use_dist and args.config == 2 and not args.no_other_configs:
+            # the tree configurations in the same run, so that one driver-timed command covers them (one Render per launch and
+            # throughput mode each; counters, event times and rooflines as for the main configuration)
+            del r
+            others = []
+            for cid, steps in ((3, 32), (4, 16)):
+                try:
+                    rec, _s, _c, rr = run_single(cid, steps, 3, args.order, torch, local_rank)
+                    del rr, _s
+                    others.append(rec)
+                except Exception as e:                                   # the main line must not be lost to a side measurement
+                    others.append({"config": cid, "error": "%s: %s" % (type(e).__name__, e)})
+            out["other_configs"] = others
         print(json.dumps(out), flush=True)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _traffic_from_profile(config):
-    """HBM bytes per launch of the trace kernel from the committed PMC pass (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get("config%d" % config, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
 
 
 if __name__ == "__main__":

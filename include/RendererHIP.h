@@ -76,6 +76,8 @@ public:
         bool AntiAliasing = false;
         uint32_t Bounces = 8;
         int TraversalOrder = RT_ORDER_AUTO;    // not in the reference: KD tree walk order, see rt_mi355x.h
+        bool PipelinedHandoff = false;         // not in the reference: Render hands the frame over one call late while its
+                                               // copy to the host runs beside the next trace (rt_map_image_pipelined)
     };
     Settings& GetSettings() { return m_settings; }
 
@@ -90,13 +92,10 @@ public:
     // Renderer::OnResize (Renderer.cpp:20-43)
     void OnResize(uint32_t width, uint32_t height)
     {
-        if (m_Image) {
-            if (m_Image->GetWidth() == width && m_Image->GetHeight() == height) return;
-            m_Image->Resize(width, height);
-        } else {
-            m_Image = std::make_shared<ImageT>(width, height, kFormat);
-        }
-        check(rt_resize(m_ctx, width, height), "rt_resize");
+        if (m_Image && m_Image->GetWidth() == width && m_Image->GetHeight() == height) return;
+        check(rt_resize(m_ctx, width, height), "rt_resize");      // first: if it throws, image and context still agree
+        if (m_Image) m_Image->Resize(width, height);
+        else m_Image = std::make_shared<ImageT>(width, height, kFormat);
         ResetFrameIndex();
     }
 
@@ -133,7 +132,8 @@ public:
 
         check(rt_render(m_ctx, m_frameindex), "rt_render");
         if (m_settings.Accumulate) m_frameindex++; else m_frameindex = 1;      // Renderer.cpp:128-131
-        const float* frame = rt_map_image(m_ctx);                               // page-locked staging owned by the library
+        // page-locked staging owned by the library
+        const float* frame = m_settings.PipelinedHandoff ? rt_map_image_pipelined(m_ctx) : rt_map_image(m_ctx);
         if (!frame) check(RT_E_HIP, "rt_map_image");
         m_Image->SetData(frame);                                                // Renderer.cpp:134
     }

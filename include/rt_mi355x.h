@@ -37,7 +37,8 @@ typedef struct { float x, y, z, radius; uint32_t material; } rt_sphere;
 /* Material without the display name (RayTracer/src/Scene.h:26-35). */
 typedef struct { float albedo[3]; float emission[3]; float roughness, transparency, ior; } rt_material;
 
-/* Renderer::Settings (RayTracer/src/Renderer.h:103-110) as plain ints.  `scene_mode` carries UseSphereScene
+/* Renderer::Settings (RayTracer/src/Renderer.h:103-110) as plain ints.  `accumulate` is carried for completeness only: the caller
+   decides the next frame index from it (Renderer.cpp:128-131) and passes that to rt_render.  `scene_mode` carries UseSphereScene
    (0 = mesh through the KD tree, 1 = spheres) and adds 2 = both, nearest wins by the strict sphere-first compare
    of Renderer.cpp:292-300.  `seed` seeds the per-(pixel, frame) pcg32 streams (the value Walnut::Random::Init
    intended, Random.h:22, is 1337).  `traversal` (no counterpart in the reference) selects the order in which the KD
@@ -99,8 +100,8 @@ typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepas
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh
-   scenes whose camera has direction.x == +0 pixels. */
-typedef struct { uint64_t launches; double total_ms; double last_ms; double prepass_total_ms; } rt_kernel_time;
+   scenes whose camera has direction.x == +0 pixels; frames = Renders those launches held (rt_render_frames puts several in one). */
+typedef struct { uint64_t launches; double total_ms; double last_ms; double prepass_total_ms; uint64_t frames; } rt_kernel_time;
 
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* Renderer::Renderer() (Renderer.cpp:16-18) on HIP device `device_id`. Returns NULL on failure. */
@@ -122,7 +123,10 @@ int rt_set_materials(rt_ctx*, const rt_material*, uint32_t n);
    tri_idx ntris*3, normals9 ntris*9 (Triangle::Normals[0..2]), tri_mat ntris.  Uploaded once. */
 int rt_set_mesh(rt_ctx*, const float* verts, uint32_t nverts, const uint32_t* tri_idx,
                 const float* normals9, const uint32_t* tri_mat, uint32_t ntris);
-/* Scene::kd_tree (Scene.h:43): the flattened host tree; requires rt_set_mesh first. */
+/* Scene::kd_tree (Scene.h:43): the flattened host tree; requires rt_set_mesh first.
+   RT_ORDER_AUTO / RT_ORDER_FRONT_TO_BACK give the reference's hits only for a tree that lists every triangle in each leaf whose
+   box it overlaps, as the reference builder does (KDTreeCPU.cpp:548-597); the upload checks that on a sample of the triangles
+   and AUTO falls back to the reference order when the check fails. */
 int rt_set_kdtree(rt_ctx*, const rt_kd_flat*);
 /* The order the next mesh frame will be walked in under the current settings and tree: RT_ORDER_REFERENCE or
    RT_ORDER_FRONT_TO_BACK (resolves RT_ORDER_AUTO). */
@@ -136,16 +140,45 @@ int rt_set_ray_dirs(rt_ctx*, const float* xyz, size_t n);
 
 /* ---- multi-GPU partition (no counterpart in the reference) ---------------------------------------- */
 /* This context renders only the 16-row bands b with b % band_count == band_index (screen-tile split);
-   (0, 1) = the whole frame. */
+   (0, 1) = the whole frame.  With rt_settings.anti_aliasing on it also traces and sums the single rows bordering its bands,
+   because the 3x3 filter (Renderer.cpp:84-124) reads them; they must be part of every frame of an accumulation, so switching
+   the filter on under a tile split takes effect from the next restart (frame index 1 or rt_reset_accum): until then
+   rt_render returns RT_E_STATE. */
 int rt_set_bands(rt_ctx*, uint32_t band_index, uint32_t band_count);
+
+/* ---- several GPUs from one process (no counterpart in the reference) ------------------------------ */
+/* A group = one context per listed device (a device may be listed more than once), holding the same scene: the caller sets
+   size, settings, scene and camera on every rt_group_ctx(g, i) alike.  Context 0 assembles and hands off the frame
+   (rt_map_image(rt_group_ctx(g, 0))).  The other GPUs write their part straight into GPU 0's memory (peer access over xGMI);
+   nothing is exchanged while frames are traced.  Returns NULL on failure (rt_last_error(NULL)). */
+typedef struct rt_group rt_group;
+rt_group*   rt_group_create(const int* device_ids, int n_devices);
+void        rt_group_destroy(rt_group*);
+int         rt_group_size(const rt_group*);
+rt_ctx*     rt_group_ctx(rt_group*, int i);
+const char* rt_group_last_error(const rt_group*);
+/* Screen-tile split, for single frames: Renders frame_index .. frame_index + n_frames - 1 with context i tracing the 16-row
+   bands b % n == i (rt_set_bands); the rows of the last frame are gathered in context 0's image.  Every pixel has one owner for
+   the whole accumulation, so the frame equals the one-GPU frame bit for bit. */
+int rt_group_render_tiles(rt_group*, uint32_t frame_index, uint32_t n_frames);
+/* Sample split, for progressive accumulation: the n * frames_per_ctx Renders frame_first .. of this call are dealt out by
+   frame index, context i taking the block frame_first + i * frames_per_ctx ..., each into its own accumulation buffer
+   (frame_first == 1 starts all of them from zero).  Then the contexts' sums are added in context order on GPU 0 --
+   ((a0 + a1) + a2) + ..., 12 B per pixel and context over xGMI -- and context 0's image is resolved from the total as frame
+   frame_first + n * frames_per_ctx - 1.  The total differs from the one-GPU sum only by the order of the additions
+   (|d| <= 1e-4 + 1e-4 |ref|).  rt_group_read_accum: that total, width*height*3 floats. */
+int rt_group_render_samples(rt_group*, uint32_t frame_first, uint32_t frames_per_ctx);
+int rt_group_read_accum(rt_group*, float* out_rgb);
 
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* Renderer::Render (Renderer.cpp:45-135) for 1-based frame index `frame_index` (m_frameindex): trace, accumulate,
    resolve, optional AA filter.  Asynchronous on the context's stream.  frame_index == 1 restarts accumulation
    (Renderer.cpp:55-56). */
 int rt_render(rt_ctx*, uint32_t frame_index);
-/* n consecutive Render calls (frame_index .. frame_index+n-1) in one launch; identical accumulation, only
-   the last frame's image is resolved. */
+/* n consecutive Render calls (frame_index .. frame_index+n-1) with the scene, camera and settings of the moment; identical
+   accumulation (the per-frame values are added in frame order), only the last frame's image is resolved.  Sphere scenes: one
+   launch.  Tree scenes: launches of up to 16 frames whose (pixel, frame) paths are drawn independently, so the lanes of the
+   chip stay busy across the frames -- several times the rate of single Renders. */
 int rt_render_frames(rt_ctx*, uint32_t frame_index, uint32_t n);
 /* Resolve only (Renderer.cpp:68-79, 84-124): rebuild the image from the accumulation buffer as if
    `frame_index` frames had been summed (used after a cross-GPU sum of accumulation buffers). */
@@ -163,6 +196,11 @@ int rt_read_image(rt_ctx*, float* out_rgba32f);
    of a copy into pageable memory, and no second host copy) and returned by address -- hand it straight to
    Walnut::Image::SetData.  Valid until the next rt_map_image / rt_resize / rt_destroy.  NULL on failure.  Synchronises. */
 const float* rt_map_image(rt_ctx*);
+/* The same hand-off without waiting for the newest frame: starts its copy into one of two page-locked buffers on a copy stream
+   of the library and returns the frame of the PREVIOUS call (the very first call returns its own), so the copy of frame k runs
+   beside the trace of frame k + 1 and a Render costs max(trace, copy) instead of their sum -- at the price of showing each frame
+   one call late.  Valid until the next rt_map_image* / rt_resize / rt_destroy. */
+const float* rt_map_image_pipelined(rt_ctx*);
 /* m_AccumulationBuffer (Renderer.h:157): width*height*3 floats. */
 int rt_read_accum(rt_ctx*, float* out_rgb);
 /* closestSphereIndex / closestTriangleIndex of the primary ray (Renderer.cpp:233-237): -1 miss, sphere index,

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <utility>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -22,7 +23,8 @@ extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* 
 extern "C" unsigned rt_trace_block(int mode);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
-extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int cached, hipStream_t s);
+extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s);
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
@@ -57,6 +59,7 @@ struct rt_ctx {
     static const int EV_RING = 64;
     hipEvent_t ev_start[EV_RING] = {}, ev_stop[EV_RING] = {}, ev_pre[EV_RING] = {};   // pre .. start = pre-pass, start .. stop = trace
     bool ev_has_pre[EV_RING] = {};
+    uint32_t ev_frames[EV_RING] = {};                 // Renders in the launch
     unsigned ev_head = 0, ev_tail = 0;               // [tail, head) are recorded and not yet read
     std::string error;
 
@@ -74,13 +77,32 @@ struct rt_ctx {
     uint32_t tri_mat_max = 0, tri_mat_max_at = 0;        // largest triangle material index and a triangle that has it (checked per frame)
 
     DevBuf<float4> d_spheres, d_materials, d_nodes, d_leafrecs, d_trishade, d_accum, d_image, d_dirs;
+    DevBuf<float4> d_slots;              // tree scenes: slot_frames planes of per-pixel radiance, one per Render of a launch
+    uint32_t slot_frames = 0;
+    // rows bordering this context's bands (tile split with the 3x3 filter on): whether their sums hold every frame since the
+    // accumulation was last restarted, i.e. whether the filter may read them
+    bool halo_complete = true;
+    bool halo_in_columns = false;        // the column-ray numbering in d_dirs.w includes the halo rows
+    bool column_cache = false;           // the pre-pass queue on the device belongs to the current camera, directions, bands and tree
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
     uint32_t last_grid_waves = 0;
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
-    float* h_image = nullptr;            // page-locked staging for rt_map_image
+    std::vector<float4> h_materials;     // packed materials as uploaded
+    // page-locked staging for the per-frame scene tables: a ring, so an upload never waits for the frame before it
+    static const int UP_RING = 4;
+    void* up_buf[UP_RING] = {}; size_t up_bytes[UP_RING] = {}; hipEvent_t up_done[UP_RING] = {}; unsigned up_next = 0;
+    // page-locked staging for rt_map_image / rt_map_image_pipelined: two buffers, filled in turn over a copy stream of its own
+    float* h_image[2] = {nullptr, nullptr};
     size_t h_image_bytes = 0;
+    hipEvent_t h_image_done[2] = {};     // the copy into h_image[i] has finished
+    bool h_image_pending[2] = {false, false};
+    unsigned h_image_next = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t frame_ready = nullptr;    // the frame to be copied is complete on the render stream
+    DevBuf<float4> d_image_back;         // pipelined hand-off: the frame being copied out while the next one is resolved into d_image
+    bool latest_in_back = false;         // ... and whether that back buffer holds the newest frame (no Render since the hand-off)
     bool use_host_dirs = false;          // d_dirs holds directions the host supplied (rt_set_ray_dirs)
     bool dirs_dirty = true;              // d_dirs must be regenerated from the camera before the next trace
 
@@ -110,7 +132,7 @@ struct rt_ctx {
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
 
-    rt_kernel_time ktime{0, 0.0, 0.0, 0.0};
+    rt_kernel_time ktime{0, 0.0, 0.0, 0.0, 0};
 };
 
 namespace {
@@ -156,7 +178,11 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.band_index = c->band_index; p.band_count = c->band_count;
     unsigned gx, gy; grid_for(c, gx, gy);
     p.tile_rows = 2u * gy;                               // two 8-row tile rows per 16-row band
-    p.n_units = ((c->width + 7) / 8) * p.tile_rows * (64u / RT_UNIT);
+    p.n_units_main = ((c->width + 7) / 8) * p.tile_rows * (64u / RT_UNIT);
+    // under a tile split the 3x3 filter reads the rows just outside each owned band: this context traces and sums those too
+    p.halo = (c->band_count > 1 && c->settings.anti_aliasing) ? 1u : 0u;
+    p.n_units = p.n_units_main + (p.halo ? gy * 2u * ((c->width + 15u) / 16u) : 0u);
+    p.slots = c->d_slots.ptr;
     for (uint32_t i = 0; i < c->n_spheres && i < RT_INLINE_SPHERES; ++i) p.sph_inline[i] = c->h_spheres[i];
     p.use_ace = c->settings.use_ace;
     p.spheres = c->d_spheres.ptr; p.sphere_mat = c->d_sphere_mat.ptr; p.materials = c->d_materials.ptr;
@@ -209,7 +235,7 @@ int collect_time(rt_ctx* c, bool all)
         HIP_TRY(c, hipEventSynchronize(c->ev_stop[i]));
         float ms = 0.0f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_start[i], c->ev_stop[i]));
-        c->ktime.launches++; c->ktime.total_ms += ms; c->ktime.last_ms = ms;
+        c->ktime.launches++; c->ktime.total_ms += ms; c->ktime.last_ms = ms; c->ktime.frames += c->ev_frames[i];
         if (c->ev_has_pre[i]) {
             HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_pre[i], c->ev_start[i]));
             c->ktime.prepass_total_ms += ms;
@@ -219,7 +245,30 @@ int collect_time(rt_ctx* c, bool all)
     return RT_OK;
 }
 
+// Host table -> device buffer on the context's stream, through the ring of page-locked staging buffers: the call returns at
+// once and the copy takes its place among the frames.  (A slot is reused only after its previous copy has finished.)
+int staged_upload(rt_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return RT_OK;
+    const int i = (int)(c->up_next++ % rt_ctx::UP_RING);
+    if (c->up_bytes[i]) HIP_TRY(c, hipEventSynchronize(c->up_done[i]));
+    if (c->up_bytes[i] < bytes) {
+        if (c->up_buf[i]) { (void)hipHostFree(c->up_buf[i]); c->up_buf[i] = nullptr; c->up_bytes[i] = 0; }
+        const size_t cap = bytes < 4096 ? 4096 : bytes;
+        hipError_t e = hipHostMalloc(&c->up_buf[i], cap, hipHostMallocDefault);
+        if (e != hipSuccess) { c->up_buf[i] = nullptr; return fail(c, RT_E_NOMEM, "hipHostMalloc(%zu): %s", cap, hipGetErrorString(e)); }
+        c->up_bytes[i] = cap;
+    }
+    memcpy(c->up_buf[i], src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dst, c->up_buf[i], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->up_done[i], c->stream));
+    return RT_OK;
+}
+
 }  // namespace
+
+// Message for rt_last_error(NULL) from the entry points that have no context.
+extern "C" __attribute__((visibility("hidden"))) void rt_internal_set_error(const char* msg) { g_create_error = msg ? msg : ""; }
 
 extern "C" {
 
@@ -236,6 +285,10 @@ rt_ctx* rt_create(int device_id)
     for (int i = 0; ok && i < rt_ctx::EV_RING; ++i)
         ok = hipEventCreate(&c->ev_start[i]) == hipSuccess && hipEventCreate(&c->ev_stop[i]) == hipSuccess &&
              hipEventCreate(&c->ev_pre[i]) == hipSuccess;
+    for (int i = 0; ok && i < rt_ctx::UP_RING; ++i) ok = hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; ok && i < 2; ++i) ok = hipEventCreateWithFlags(&c->h_image_done[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+         hipEventCreateWithFlags(&c->frame_ready, hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         fail(nullptr, RT_E_HIP, "stream/event creation failed on device %d", device_id);
         rt_destroy(c); return nullptr;
@@ -250,7 +303,7 @@ rt_ctx* rt_create(int device_id)
         c->d_park_count.resize(2) != hipSuccess || hipMemset(c->d_park_count.ptr, 0, 8) != hipSuccess ||
         c->d_park_flags.resize(RT_PARK_SLOTS) != hipSuccess || hipMemset(c->d_park_flags.ptr, 0, 4 * RT_PARK_SLOTS) != hipSuccess ||
         c->d_park_list.resize(RT_PARK_FAMILIES * RT_PARK_SLOTS) != hipSuccess || c->d_park_info.resize(3 * RT_PARK_FAMILIES) != hipSuccess ||
-        c->d_park_paths.resize(2 * RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
+        c->d_park_paths.resize(2 * (size_t)RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
         c->d_column_stats.resize(3) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 24) != hipSuccess ||
@@ -285,7 +338,17 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
-    if (c->h_image) (void)hipHostFree(c->h_image);
+    c->d_slots.release(); c->d_image_back.release();
+    for (int i = 0; i < rt_ctx::UP_RING; ++i) {
+        if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
+        if (c->up_buf[i]) (void)hipHostFree(c->up_buf[i]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_image_done[i]) (void)hipEventDestroy(c->h_image_done[i]);
+        if (c->h_image[i]) (void)hipHostFree(c->h_image[i]);
+    }
+    if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -308,15 +371,26 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
     if (w == c->width && h == c->height) return RT_OK;           // Renderer.cpp:23-24
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
     const size_t n = (size_t)w * h;
-    HIP_TRY(c, c->d_accum.resize(n));
-    HIP_TRY(c, c->d_image.resize(n));
-    HIP_TRY(c, c->d_ids.resize(n));
-    HIP_TRY(c, c->d_dirs.resize(n));
-    HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, n * sizeof(float4), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_image.ptr, 0, n * sizeof(float4), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_ids.ptr, 0xFF, n * sizeof(int32_t), c->stream));
-    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true;
+    // all or nothing: a context whose buffers could not all be had has no frame (width = height = 0) and every call that
+    // needs one returns RT_E_STATE, instead of kernels running over buffers of the wrong size
+    c->width = 0; c->height = 0;
+    c->d_slots.release(); c->slot_frames = 0; c->d_image_back.release(); c->latest_in_back = false;
+    for (int i = 0; i < 2; ++i) { if (c->h_image[i]) { (void)hipHostFree(c->h_image[i]); c->h_image[i] = nullptr; } c->h_image_pending[i] = false; }
+    c->h_image_bytes = 0;
+    hipError_t e = c->d_accum.resize(n);
+    if (e == hipSuccess) e = c->d_image.resize(n);
+    if (e == hipSuccess) e = c->d_ids.resize(n);
+    if (e == hipSuccess) e = c->d_dirs.resize(n);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_accum.ptr, 0, n * sizeof(float4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_image.ptr, 0, n * sizeof(float4), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_ids.ptr, 0xFF, n * sizeof(int32_t), c->stream);
+    if (e != hipSuccess) {
+        c->d_accum.release(); c->d_image.release(); c->d_ids.release(); c->d_dirs.release();
+        return fail(c, e == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_HIP, "rt_resize(%u, %u): %s", w, h, hipGetErrorString(e));
+    }
+    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->halo_complete = true;
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -333,21 +407,26 @@ int rt_set_settings(rt_ctx* c, const rt_settings* s)
 int rt_set_spheres(rt_ctx* c, const rt_sphere* sp, uint32_t n)
 {
     if (!c || (n && !sp)) return RT_E_ARG;
-    DeviceGuard g(c->device);
-    std::vector<float4>& packed = c->h_spheres;
-    packed.resize(n);
-    c->h_sphere_mat.resize(n);
+    std::vector<float4> packed(n);
+    std::vector<uint32_t> mat(n);
     for (uint32_t i = 0; i < n; ++i) {
         packed[i] = make_float4(sp[i].x, sp[i].y, sp[i].z, sp[i].radius * sp[i].radius);   // Renderer.cpp:257's r*r
-        c->h_sphere_mat[i] = sp[i].material;
+        mat[i] = sp[i].material;
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_spheres.resize(n));
-    HIP_TRY(c, c->d_sphere_mat.resize(n));
-    if (n) {
-        HIP_TRY(c, hipMemcpy(c->d_spheres.ptr, packed.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(c, hipMemcpy(c->d_sphere_mat.ptr, c->h_sphere_mat.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the UI sends the tables every frame (RaytracerApp.cpp:283-331) and changes them rarely: nothing to do when they are the same
+    if (n == c->n_spheres && c->d_spheres.count == n && (!n || (memcmp(packed.data(), c->h_spheres.data(), n * sizeof(float4)) == 0 &&
+                                                                 memcmp(mat.data(), c->h_sphere_mat.data(), n * sizeof(uint32_t)) == 0)))
+        return RT_OK;
+    DeviceGuard g(c->device);
+    if (c->d_spheres.count != n) {                               // another number of spheres: new buffers (rare)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->d_spheres.resize(n));
+        HIP_TRY(c, c->d_sphere_mat.resize(n));
     }
+    c->n_spheres = 0;                                            // until both copies are queued
+    if (int rc = staged_upload(c, c->d_spheres.ptr, packed.data(), n * sizeof(float4))) return rc;
+    if (int rc = staged_upload(c, c->d_sphere_mat.ptr, mat.data(), n * sizeof(uint32_t))) return rc;
+    c->h_spheres.swap(packed); c->h_sphere_mat.swap(mat);
     c->n_spheres = n;
     return RT_OK;
 }
@@ -355,16 +434,23 @@ int rt_set_spheres(rt_ctx* c, const rt_sphere* sp, uint32_t n)
 int rt_set_materials(rt_ctx* c, const rt_material* m, uint32_t n)
 {
     if (!c || (n && !m)) return RT_E_ARG;
-    DeviceGuard g(c->device);
     std::vector<float4> packed(3 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i) {
         packed[3 * i] = make_float4(m[i].albedo[0], m[i].albedo[1], m[i].albedo[2], m[i].roughness);
         packed[3 * i + 1] = make_float4(m[i].emission[0], m[i].emission[1], m[i].emission[2], m[i].transparency);
         packed[3 * i + 2] = make_float4(m[i].ior, 0.0f, 0.0f, 0.0f);
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_materials.resize(3 * (size_t)n));
-    if (n) HIP_TRY(c, hipMemcpy(c->d_materials.ptr, packed.data(), packed.size() * sizeof(float4), hipMemcpyHostToDevice));
+    if (n == c->n_materials && c->d_materials.count == packed.size() &&
+        (!n || memcmp(packed.data(), c->h_materials.data(), packed.size() * sizeof(float4)) == 0))
+        return RT_OK;
+    DeviceGuard g(c->device);
+    if (c->d_materials.count != packed.size()) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, c->d_materials.resize(packed.size()));
+    }
+    c->n_materials = 0;
+    if (int rc = staged_upload(c, c->d_materials.ptr, packed.data(), packed.size() * sizeof(float4))) return rc;
+    c->h_materials.swap(packed);
     c->n_materials = n;
     return RT_OK;
 }
@@ -395,6 +481,7 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->n_tris = ntris; c->n_verts = nverts;
     c->n_nodes = 0; c->n_refs = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
+    c->column_cache = false;
     return RT_OK;
 }
 
@@ -555,7 +642,7 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
         for (int a = 0; a < 3; ++a) c->root_center[a] = kd->center[a];
         c->root_reach = reach[0] + reach[1] + reach[2];
     }
-    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition;
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->column_cache = false;
     return RT_OK;
 }
 
@@ -571,6 +658,7 @@ int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const
     if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
     // directions are regenerated only when the matrices change (Camera.cpp:96-100,113-114)
     if (!c->have_camera || memcmp(c->inv_proj, inv_proj, 64) != 0 || memcmp(c->inv_view, inv_view, 64) != 0) c->dirs_dirty = true;
+    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false;     // the column rays start at the camera
     memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
     c->have_camera = true;
     return RT_OK;
@@ -620,7 +708,9 @@ int ensure_columns(rt_ctx* c, RtParams& p)
         HIP_TRY(c, c->d_column_block.resize(blocks));
         p.column_block = c->d_column_block.ptr;
     }
+    if (c->halo_in_columns != (p.halo != 0u)) c->columns_dirty = true;      // the rows bordering the bands joined or left the frame
     if (!c->columns_dirty) return RT_OK;
+    c->column_cache = false; c->halo_in_columns = p.halo != 0u;
     HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -652,34 +742,52 @@ int trace_grid(rt_ctx* c, int mode, bool stats, bool ordered, uint32_t n_units, 
 
 }  // namespace
 
-int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
-{
-    if (!c) return RT_E_ARG;
-    if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
-    if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
-    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render before rt_set_camera (the camera position is needed even with rt_set_ray_dirs)");
-    const int mode = c->settings.scene_mode;
-    if (int rc = validate_scene(c, mode)) return rc;
-    DeviceGuard g(c->device);
-    if (int rc = collect_time(c, false)) return rc;
+namespace {
 
+// Frames frame_index .. frame_index + n - 1 in one launch of the trace kernel (tree scenes: n <= RT_MAX_LAUNCH_FRAMES).
+int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
+{
+    const int mode = c->settings.scene_mode;
+    const bool tree = mode != RT_SCENE_SPHERES;
     RtParams p; fill_params(c, p, frame_index, n);
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
+    // The 3x3 filter under a tile split reads the sums of the rows bordering this context's bands.  They are traced and summed
+    // like its own rows while the filter is on; switched on in the middle of an accumulation they would lack the earlier frames.
+    if (p.halo && frame_index != 1u && !c->halo_complete)
+        return fail(c, RT_E_STATE, "anti_aliasing under a tile split needs the rows bordering this context's bands in every frame of the "
+                                   "accumulation: restart it (frame index 1 or rt_reset_accum) after switching the filter on");
+    if (c->band_count > 1) c->halo_complete = p.halo ? (frame_index == 1u || c->halo_complete) : false;
+    if (tree) {
+        const size_t plane = (size_t)c->width * c->height;
+        if (c->slot_frames < n) {                       // one plane of radiance slots per Render of a launch
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            c->slot_frames = 0;
+            hipError_t e = c->d_slots.resize(plane * n);
+            if (e != hipSuccess) return fail(c, RT_E_NOMEM, "%u planes of %zu pixel slots: %s", n, plane, hipGetErrorString(e));
+            c->slot_frames = n;
+        }
+        p.slots = c->d_slots.ptr;
+    }
     if (int rc = ensure_dirs(c, p)) return rc;
-    if (mode != RT_SCENE_SPHERES) { if (int rc = ensure_columns(c, p)) return rc; }
-    const bool ordered = mode != RT_SCENE_SPHERES && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
+    if (tree) { if (int rc = ensure_columns(c, p)) return rc; }
+    const bool ordered = tree && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     unsigned grid;
-    if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units, grid)) return rc;
+    if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units * (tree ? n : 1u), grid)) return rc;
     // events: [pre, start) = the column pre-pass (mesh scenes whose camera has direction.x == +0 pixels), [start, stop) = the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
-    c->ev_has_pre[ev] = mode != RT_SCENE_SPHERES && c->n_columns;
+    c->ev_has_pre[ev] = tree && c->n_columns;
     if (c->ev_has_pre[ev]) {
         HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
-        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
+        // Which leaf records the column rays can hit depends on the camera, the directions and the tree only: found once and kept
+        // (the queue of undecided (record, 16 rays) pairs); every launch repeats the triangle tests on that queue.  The counting
+        // kernels always run the whole pre-pass: their counters describe what the reference's walk costs for these rays.
+        const bool cached = c->column_cache && !c->stats;
+        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, cached ? 1 : 0, c->stream));
+        c->column_cache = true;
     } else p.column_best = nullptr;
     // sphere frames resolve inside the trace kernel; the 3x3 filter needs the neighbours' sums and keeps the separate pass
-    const bool fused = mode == RT_SCENE_SPHERES && !c->settings.anti_aliasing;
+    const bool fused = !tree && !c->settings.anti_aliasing;
     p.fuse_resolve = fused ? 1u : 0u;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
@@ -687,10 +795,13 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
     // the rare walk by a wave, except in large trees.
     if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
-    const bool parking = mode != RT_SCENE_SPHERES && c->n_nodes >= p.park_min_nodes;
+    const bool parking = tree && c->n_nodes >= p.park_min_nodes;
     if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
+    // the unit tickets of tree scenes start at zero for every launch that draws units
+    if (tree) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
     HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
+    c->ev_frames[ev] = n;
     c->ev_head++;
     if (parking) {
         // The paths the launch parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a
@@ -717,8 +828,32 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
             HIP_TRY(c, hipStreamSynchronize(c->stream));
         }
     }
-    if (!fused) HIP_TRY(c, rt_launch_resolve(&p, frame_index + n - 1, gx, gy, c->stream));
-    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index + n - 1, gx, gy, c->stream));
+    const uint32_t frame_last = frame_index + n - 1u;
+    c->latest_in_back = false;
+    if (tree) HIP_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
+    else if (!fused) HIP_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
+{
+    if (!c) return RT_E_ARG;
+    if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
+    if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
+    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render before rt_set_camera (the camera position is needed even with rt_set_ray_dirs)");
+    const int mode = c->settings.scene_mode;
+    if (int rc = validate_scene(c, mode)) return rc;
+    DeviceGuard g(c->device);
+    if (int rc = collect_time(c, false)) return rc;
+    // sphere scenes: a lane keeps its pixel for all n frames, whatever n; tree scenes: at most RT_MAX_LAUNCH_FRAMES planes of slots
+    const uint32_t per_launch = mode == RT_SCENE_SPHERES ? n : (uint32_t)RT_MAX_LAUNCH_FRAMES;
+    for (uint32_t done = 0; done < n; done += per_launch) {
+        const uint32_t k = n - done < per_launch ? n - done : per_launch;
+        if (int rc = render_launch(c, frame_index + done, k)) return rc;
+    }
     return RT_OK;
 }
 
@@ -732,6 +867,7 @@ int rt_resolve(rt_ctx* c, uint32_t frame_index)
     RtParams p; fill_params(c, p, frame_index, 1);
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;
+    c->latest_in_back = false;
     HIP_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
     if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;
@@ -743,6 +879,7 @@ int rt_reset_accum(rt_ctx* c)
     if (!c->width) return fail(c, RT_E_STATE, "rt_reset_accum before rt_resize");
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, (size_t)c->width * c->height * sizeof(float4), c->stream));
+    c->halo_complete = true;                             // an empty sum is complete for every row
     return RT_OK;
 }
 
@@ -759,9 +896,32 @@ int rt_read_image(rt_ctx* c, float* out)
     if (!c || !out) return RT_E_ARG;
     if (!c->width) return fail(c, RT_E_STATE, "no frame");
     DeviceGuard g(c->device);
-    HIP_TRY(c, hipMemcpyAsync(out, c->d_image.ptr, (size_t)c->width * c->height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    const float4* frame = c->latest_in_back ? c->d_image_back.ptr : c->d_image.ptr;
+    HIP_TRY(c, hipMemcpyAsync(out, frame, (size_t)c->width * c->height * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
     return rt_sync(c);
 }
+
+namespace {
+
+// The two page-locked frame buffers, sized for the current frame.
+int ensure_host_frames(rt_ctx* c, size_t bytes)
+{
+    if (c->h_image_bytes == bytes && c->h_image[0] && c->h_image[1]) return RT_OK;
+    (void)hipStreamSynchronize(c->copy_stream);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_image[i]) { (void)hipHostFree(c->h_image[i]); c->h_image[i] = nullptr; }
+        c->h_image_pending[i] = false;
+    }
+    c->h_image_bytes = 0;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipHostMalloc((void**)&c->h_image[i], bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { c->h_image[i] = nullptr; return fail(c, RT_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    }
+    c->h_image_bytes = bytes;
+    return RT_OK;
+}
+
+}  // namespace
 
 const float* rt_map_image(rt_ctx* c)
 {
@@ -769,16 +929,46 @@ const float* rt_map_image(rt_ctx* c)
     if (!c->width) { fail(c, RT_E_STATE, "no frame"); return nullptr; }
     DeviceGuard g(c->device);
     const size_t bytes = (size_t)c->width * c->height * sizeof(float4);
-    if (c->h_image_bytes != bytes) {
-        if (c->h_image) { (void)hipStreamSynchronize(c->stream); (void)hipHostFree(c->h_image); c->h_image = nullptr; c->h_image_bytes = 0; }
-        hipError_t e = hipHostMalloc((void**)&c->h_image, bytes, hipHostMallocDefault);
-        if (e != hipSuccess) { fail(c, RT_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); c->h_image = nullptr; return nullptr; }
-        c->h_image_bytes = bytes;
+    if (ensure_host_frames(c, bytes) != RT_OK) return nullptr;
+    if (c->h_image_pending[0] || c->h_image_pending[1]) {          // copies of a pipelined hand-off still under way
+        if (hipStreamSynchronize(c->copy_stream) != hipSuccess) { fail(c, RT_E_HIP, "hipStreamSynchronize(copy stream)"); return nullptr; }
+        c->h_image_pending[0] = c->h_image_pending[1] = false;
     }
-    hipError_t e = hipMemcpyAsync(c->h_image, c->d_image.ptr, bytes, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e = hipMemcpyAsync(c->h_image[0], c->latest_in_back ? c->d_image_back.ptr : c->d_image.ptr, bytes, hipMemcpyDeviceToHost, c->stream);
     if (e != hipSuccess) { fail(c, RT_E_HIP, "hipMemcpyAsync: %s", hipGetErrorString(e)); return nullptr; }
     if (rt_sync(c) != RT_OK) return nullptr;
-    return c->h_image;
+    return c->h_image[0];
+}
+
+const float* rt_map_image_pipelined(rt_ctx* c)
+{
+    if (!c) return nullptr;
+    if (!c->width) { fail(c, RT_E_STATE, "no frame"); return nullptr; }
+    DeviceGuard g(c->device);
+    const size_t n = (size_t)c->width * c->height, bytes = n * sizeof(float4);
+    if (ensure_host_frames(c, bytes) != RT_OK) return nullptr;
+    if (c->d_image_back.count != n) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess || c->d_image_back.resize(n) != hipSuccess) {
+            fail(c, RT_E_NOMEM, "second frame buffer of %zu bytes", bytes); return nullptr;
+        }
+    }
+    // The finished frame becomes the back buffer and is copied out over the copy stream; later Renders resolve into the other
+    // buffer, whose own copy (two calls ago) was waited for before that call returned.
+    const unsigned i = c->h_image_next & 1u;
+    hipError_t e = hipEventRecord(c->frame_ready, c->stream);
+    std::swap(c->d_image.ptr, c->d_image_back.ptr);
+    c->latest_in_back = true;
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->frame_ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->h_image[i], c->d_image_back.ptr, bytes, hipMemcpyDeviceToHost, c->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(c->h_image_done[i], c->copy_stream);
+    if (e != hipSuccess) { fail(c, RT_E_HIP, "pipelined frame copy: %s", hipGetErrorString(e)); return nullptr; }
+    c->h_image_pending[i] = true;
+    c->h_image_next++;
+    const unsigned ret = c->h_image_pending[1u - i] ? 1u - i : i;   // the frame of the call before; the very first call waits for its own
+    if (hipEventSynchronize(c->h_image_done[ret]) != hipSuccess) { fail(c, RT_E_HIP, "hipEventSynchronize(frame copy)"); return nullptr; }
+    if (ret != i) c->h_image_pending[ret] = false;
+    if (collect_time(c, false) != RT_OK) return nullptr;
+    return c->h_image[ret];
 }
 
 int rt_read_accum(rt_ctx* c, float* out_rgb)
@@ -877,11 +1067,30 @@ int rt_reset_kernel_time(rt_ctx* c)
     if (!c) return RT_E_ARG;
     DeviceGuard g(c->device);
     if (int rc = collect_time(c, true)) return rc;
-    c->ktime = rt_kernel_time{0, 0.0, 0.0, 0.0};
+    c->ktime = rt_kernel_time{0, 0.0, 0.0, 0.0, 0};
+    return RT_OK;
+}
+
+// ---- for rt_group.hip (not part of the C ABI) ----
+__attribute__((visibility("hidden"))) hipStream_t rt_internal_stream(rt_ctx* c) { return c->stream; }
+__attribute__((visibility("hidden"))) int rt_internal_device(const rt_ctx* c) { return c->device; }
+__attribute__((visibility("hidden"))) void rt_internal_size(const rt_ctx* c, uint32_t* w, uint32_t* h) { *w = c->width; *h = c->height; }
+// Resolve (and filter) the frame from sums that are not this context's own buffer: the sum over a group's contexts.
+__attribute__((visibility("hidden"))) int rt_internal_resolve_from(rt_ctx* c, const void* accum_float4, uint32_t frame_index)
+{
+    if (!c->width || !frame_index) return fail(c, RT_E_STATE, "resolve before rt_resize");
+    DeviceGuard g(c->device);
+    RtParams p; fill_params(c, p, frame_index, 1);
+    p.accum = const_cast<float4*>(static_cast<const float4*>(accum_float4));
+    unsigned gx, gy; grid_for(c, gx, gy);
+    if (!gy) return RT_OK;
+    c->latest_in_back = false;
+    HIP_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;
 }
 
 void* rt_device_accum(rt_ctx* c) { return c ? (void*)c->d_accum.ptr : nullptr; }
-void* rt_device_image(rt_ctx* c) { return c ? (void*)c->d_image.ptr : nullptr; }
+void* rt_device_image(rt_ctx* c) { return c ? (void*)(c->latest_in_back ? c->d_image_back.ptr : c->d_image.ptr) : nullptr; }
 
 }  // extern "C"

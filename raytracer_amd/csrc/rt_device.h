@@ -25,12 +25,14 @@
 #endif
 #define RT_SPHERE_POOL_SLOTS 128   // paths waiting for another wave (at most 63 + RT_SPHERE_MERGE at a time)
 #define RT_SPHERE_POOL_WORDS 20    // 32-bit words of a sphere-scene path
-#define RT_PARK_SLOTS 4096         // bounce rays the tree cannot prune that one round can hand to whole-chip kernels
+#define RT_PARK_SLOTS 16384        // bounce rays the tree cannot prune that one round can hand to whole-chip kernels (a launch of 16 frames of
+                                   // spheres + mesh at 4K parks about 5,600)
 #define RT_PARK_CHUNK 1024         // ... of which this many wait in LDS at a time while the records stream past
 #define RT_PARK_FAMILIES 2         // ... grouped by (origin.x, sign of the zero): rays of a family visit the same nodes
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_MIN_NODES_MIXED (1u << 12)   // ... and with spheres and mesh together, where such rays come by the hundred
-#define RT_PARK_WORDS 6            // float4 per parked path
+#define RT_PARK_WORDS 5            // float4 per parked path
+#define RT_MAX_LAUNCH_FRAMES 16    // tree scenes: Renders one launch can hold (a plane of per-pixel radiance slots each)
 #define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
 #ifndef RT_NEAR_TIES
 #define RT_NEAR_TIES 1             /* 0 compiles the near-tie test and the repeat walk out (A/B measurements) */
@@ -69,7 +71,7 @@
 #define RT_KEEP 2                  /* paths a wave keeps for itself when it gives others away */
 #endif
 #define RT_POOL_SLOTS 16           // paths the pool holds while they change waves
-#define RT_POOL_WORDS 41           // 32-bit words of one path's state
+#define RT_POOL_WORDS 38           // 32-bit words of one path's state
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
 #define RT_WAVE_CLOCK_WORDS 6
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
@@ -114,6 +116,9 @@ struct RtParams {
     uint32_t n_nodes;
     uint32_t band_index, band_count;       // screen-tile split: this context renders bands b*band_count + band_index
     uint32_t tile_rows, n_units;           // 8-row tile rows / RT_UNIT-pixel work units in the bands this context renders
+    uint32_t n_units_main;                 // ... of which the first n_units_main are the 8x2 strips of the owned bands; the rest are 16x1
+                                           // strips of the rows that border an owned band (`halo`: the 3x3 filter reads them under a tile split)
+    uint32_t halo;
     uint32_t* work_heads;                  // RT_WORK_HEADS ticket counters (RT_HEAD_STRIDE words apart), zero before every trace launch
     int32_t  use_ace;
     uint32_t fuse_resolve;                  // sphere trace kernel: each workgroup also resolves its share of the image
@@ -127,6 +132,8 @@ struct RtParams {
     float4* dirs_out;                       // raygen kernel's output (same buffer)
     float4* accum;
     float4* image;
+    float4* slots;                          // tree scenes: n_frames planes of width*height { radiance.rgb, walk steps } -- the value each
+                                            // Render of the launch adds to its pixel, summed into `accum` in frame order by the resolve pass
     int32_t* primary_ids;                   // optional
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
@@ -155,7 +162,7 @@ struct RtParams {
     // whole-chip kernels find the hit (same reach + test as for the column rays, one ray at a time), a one-workgroup launch of
     // the trace kernel (resume != 0) continues the paths.
     uint32_t* park_count;                    // paths parked by the running trace launch (may exceed RT_PARK_SLOTS: the excess was not parked)
-    float4*   park_paths;                    // RT_PARK_WORDS float4 per slot: origin, direction, contribution, colour, {rng lo, rng hi, bounce, pixel}, {accumulated rgb, frame}
+    float4*   park_paths;                    // RT_PARK_WORDS float4 per slot: {origin, column slot} {direction, bounce} {contribution, pixel} {colour, frame} {rng lo, rng hi}
     const uint32_t* resume_count;            // the list being resolved / resumed (what the previous launch parked): same layout
     const float4*   resume_paths;
     unsigned long long* park_best;           // per slot of that list: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss

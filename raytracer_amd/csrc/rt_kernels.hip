@@ -730,10 +730,20 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const Scen
     return shade_hit<RT_MODE_SPHERES, in_lds>(s, p, lds, primary_id, first, last, tS, iS, th);
 }
 
-// Pixel `slot` of work unit `unit`: units are the four 8x2 strips of each 8x8 tile of the 16-row bands this context
-// renders; tiles are numbered down the columns of tiles.
+// Pixel `slot` of work unit `unit`.  Units below n_units_main are the four 8x2 strips of each 8x8 tile of the 16-row bands this
+// context renders; tiles are numbered down the columns of tiles.  Units from n_units_main on (only under a tile split with the
+// 3x3 filter on) are 16x1 strips of the rows just below and just above each owned band: the filter reads their sums.
 __device__ __forceinline__ bool unit_pixel(const RtParams& p, uint32_t unit, uint32_t slot, uint32_t& pixel)
 {
+    if (unit >= p.n_units_main) {
+        const uint32_t hu = unit - p.n_units_main, chunks = (p.width + 15u) / 16u;
+        const uint32_t r = hu / chunks, chunk = hu - r * chunks;
+        const uint32_t band = (r >> 1) * p.band_count + p.band_index;
+        const uint32_t x = chunk * 16u + slot;
+        const uint32_t y = (r & 1u) ? band * RT_TILE + RT_TILE : band * RT_TILE - 1u;      // band 0, lower side: wraps, rejected below
+        pixel = y * p.width + x;
+        return x < p.width && y < p.height;
+    }
     const uint32_t tile = unit >> 2;
     const uint32_t within = ((unit & 3u) << 4) | slot;
     const uint32_t tcol = tile / p.tile_rows, trow = tile - tcol * p.tile_rows;
@@ -742,6 +752,16 @@ __device__ __forceinline__ bool unit_pixel(const RtParams& p, uint32_t unit, uin
     const uint32_t y = band * RT_TILE + (trow & 1u) * 8u + (within >> 3);
     pixel = y * p.width + x;
     return x < p.width && y < p.height;
+}
+
+// Row y belongs to this context: one of its bands, or (with the halo on) a row bordering one.
+__device__ __forceinline__ bool row_rendered(const RtParams& p, uint32_t y)
+{
+    if (((y / RT_TILE) % p.band_count) == p.band_index) return true;
+    if (!p.halo) return false;
+    const uint32_t in_band = y % RT_TILE;
+    if (in_band == RT_TILE - 1u && y + 1u < p.height && (((y + 1u) / RT_TILE) % p.band_count) == p.band_index) return true;
+    return in_band == 0u && y > 0u && (((y - 1u) / RT_TILE) % p.band_count) == p.band_index;
 }
 
 }  // namespace
@@ -836,8 +856,7 @@ __device__ __forceinline__ bool is_column_pixel(const RtParams& p, uint32_t pixe
     if (pixel >= p.width * p.height) return false;
     const uint32_t y = pixel / p.width;
     d = p.dirs_out[pixel];
-    const bool owned = ((y / RT_TILE) % p.band_count) == p.band_index;
-    return owned && __float_as_uint(d.x) == 0u;                     // +0 exactly; -0 rays take the in-kernel path
+    return row_rendered(p, y) && __float_as_uint(d.x) == 0u;                     // +0 exactly; -0 rays take the in-kernel path
 }
 
 __global__ __launch_bounds__(256) void rt_column_count_kernel(RtParams p)
@@ -968,10 +987,7 @@ __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
     F3 O, D; uint32_t count;
     if (!reach_ray(p, O, D, count)) return;
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
-    if (p.ray_slot < 0) {
-        if (gid < count) p.column_best[gid] = ~0ull;                // fresh results for this frame (grid covers column_cap)
-        if (gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }
-    }
+    if (p.ray_slot < 0 && gid == 0u) { *p.column_queue_count = 0u; *p.column_flags = 0u; }      // a new queue is about to be built
     const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
     bool box; float tNear;
     uint32_t m = column_kill_end(p, gid, O, invD, box, tNear);
@@ -1171,6 +1187,14 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
     }
 }
 
+// Fresh results for the column rays of this launch (the grid covers column_cap slots).
+__global__ __launch_bounds__(256) void rt_column_reset_kernel(RtParams p)
+{
+    const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid < count) p.column_best[gid] = ~0ull;
+}
+
 // The real triangle test for the queued (record, 16 rays) pairs: 16 lanes per pair.
 __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 {
@@ -1196,9 +1220,11 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 
 // The trace kernels are persistent: the grid is sized to what the chip holds at once and every wave works through 16-pixel
 // units (the four 8x2 strips of each 8x8 tile).  Each loop iteration advances every live lane by one bounce; lanes whose path
-// ended take the next (pixel, frame) before the next iteration, so the wave stays full until the frame runs dry.  A lane keeps
-// its pixel for all n_frames frames and adds them in frame order, which makes the sum identical to n_frames separate Render
-// calls.  How units reach the waves depends on the scene:
+// ended take the next (pixel, frame) before the next iteration, so the wave stays full until the launch runs dry.  In sphere
+// scenes a lane keeps its pixel for all n_frames frames of the launch and adds them in frame order; in tree scenes every
+// (pixel, frame) is a path of its own, drawn independently, whose radiance goes to the pixel's slot of that frame, and the
+// resolve pass adds the slots in frame order.  Either way the sum is that of n_frames separate Render calls, bit for bit.
+// How units reach the waves depends on the scene:
 //   spheres only : every region of the image costs about the same, so each workgroup owns a fixed share of the units (workgroup b
 //                  takes units b, b + workgroups, ...) and its 16 waves draw them from a counter in LDS.  The waves of a SIMD do
 //                  not advance at the same rate (the oldest wave is served first), so a fixed share per WAVE leaves each SIMD
@@ -1211,8 +1237,11 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 //                  XCDs: one head per XCD) and moves on to the other heads when its own is exhausted.  Units are taken whole,
 //                  one per 16 idle lanes and all of a refill with one atomic, so a wave never owns pixels it cannot start at
 //                  once -- otherwise the last units trickle through a few lanes of one wave while the rest of the chip idles.
-__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h) { return (p.n_units + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS; }
-__device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t) { return h + RT_WORK_HEADS * t; }
+// A launch of n_frames Renders hands out (unit, frame) pairs: head h owns units h, h + 8, ... and its ticket t is frame t % n_frames
+// of unit h + 8 (t / n_frames), so the tickets of one refill are consecutive frames of the same pixels: their primary rays are
+// the same ray and walk the same nodes side by side.
+__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h) { return ((p.n_units + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS) * p.n_frames; }
+__device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t) { return h + RT_WORK_HEADS * (t / p.n_frames); }
 
 template <bool STATS, bool LDS_SCENE>
 __device__ __forceinline__ void sphere_body(const RtParams& p)
@@ -1431,9 +1460,9 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
 
     uint32_t phase = PH_IDLE;
     uint32_t pixel = 0, frame = 0, path_steps = 0;
-    F3 acc = f3(0.0f, 0.0f, 0.0f);
     Path s;
     s.O = s.D = s.contribution = s.finalColor = f3(0.0f, 0.0f, 0.0f); s.rng = 0; s.bounce = 0; s.column_slot = 0;
+    const size_t plane = (size_t)p.width * p.height;        // pixels per slot plane
     // the bounce in flight: sphere hit, closest triangle so far, cursors of the walk
     float tS = FLT_MAX; int iS = -1;
     Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
@@ -1453,14 +1482,13 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         auto F = [&](float& v) { if (save) pool.words[i][slot] = __float_as_uint(v); else v = __uint_as_float(pool.words[i][slot]); ++i; };
         uint32_t rng_lo = (uint32_t)s.rng, rng_hi = (uint32_t)(s.rng >> 32), sphere = (uint32_t)iS, tri = (uint32_t)th.id, flag = wflag ? 1u : 0u;
         U(phase); U(pixel); U(frame); U(path_steps);
-        F(acc.x); F(acc.y); F(acc.z);
         F(s.O.x); F(s.O.y); F(s.O.z); F(s.D.x); F(s.D.y); F(s.D.z);
         F(s.contribution.x); F(s.contribution.y); F(s.contribution.z); F(s.finalColor.x); F(s.finalColor.y); F(s.finalColor.z);
         U(rng_lo); U(rng_hi); U(s.bounce); U(s.column_slot);
         F(tS); U(sphere); F(th.t); U(tri); F(th.u); F(th.v);
         U(wnode); U(wrec); U(wbest); U(wsteps); F(wtol); F(wprune); U(flag);
         F(winvD.x); F(winvD.y); F(winvD.z); U(woct);
-        static_assert(RT_POOL_WORDS == 41, "path_transfer moves 41 words");
+        static_assert(RT_POOL_WORDS == 38, "path_transfer moves 38 words");
         if (!save) {
             s.rng = ((unsigned long long)rng_hi << 32) | (unsigned long long)rng_lo;
             iS = (int)sphere; th.id = (int32_t)tri; wflag = flag != 0u;
@@ -1476,13 +1504,13 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         resume_slot = wave * 64u + lane;
         if (resume_slot < n_parked) {
             const float4* q = p.resume_paths + RT_PARK_WORDS * resume_slot;
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
+            static_assert(RT_PARK_WORDS == 5, "a parked path is five float4");
             s.O = f3(q0.x, q0.y, q0.z); s.column_slot = __float_as_uint(q0.w);
             s.D = f3(q1.x, q1.y, q1.z); s.bounce = __float_as_uint(q1.w);
             s.contribution = f3(q2.x, q2.y, q2.z); pixel = __float_as_uint(q2.w);
             s.finalColor = f3(q3.x, q3.y, q3.z); frame = __float_as_uint(q3.w);
-            acc = f3(q4.x, q4.y, q4.z);
-            s.rng = ((unsigned long long)__float_as_uint(q5.y) << 32) | (unsigned long long)__float_as_uint(q5.x);
+            s.rng = ((unsigned long long)__float_as_uint(q4.y) << 32) | (unsigned long long)__float_as_uint(q4.x);
             phase = PH_BEGIN; parked_hit_ready = true;
         }
     }
@@ -1498,13 +1526,11 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             t = __builtin_amdgcn_readfirstlane(t);
             const uint32_t got = t < count ? (want < count - t ? want : count - t) : 0u;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            // ticket t of head h is unit h + 8 t; idle lane number `rank` takes pixel rank % 16 of the rank / 16-th unit taken
+            // idle lane number `rank` takes pixel rank % 16 of the rank / 16-th ticket taken (see head_unit)
             if (phase == PH_IDLE && rank < got * RT_UNIT && unit_pixel(p, head_unit(p, head, t + rank / RT_UNIT), rank % RT_UNIT, pixel)) {
                 phase = PH_BEGIN;
-                frame = 0;
-                acc = f3(0.0f, 0.0f, 0.0f);                 // frame index 1 restarts accumulation (Renderer.cpp:55-56)
-                if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
-                path_begin(s, p, pixel, p.frame_first);
+                frame = (t + rank / RT_UNIT) % p.n_frames;
+                path_begin(s, p, pixel, p.frame_first + frame);
             }
             if (got < want) { heads_empty++; head = (head + 1u) % RT_WORK_HEADS; }
             need = __ballot(phase == PH_IDLE);              // what is still idle: lanes without a unit, and pixels outside the frame
@@ -1612,8 +1638,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     q[1] = make_float4(s.D.x, s.D.y, s.D.z, __uint_as_float(s.bounce));
                     q[2] = make_float4(s.contribution.x, s.contribution.y, s.contribution.z, __uint_as_float(pixel));
                     q[3] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, __uint_as_float(frame));
-                    q[4] = make_float4(acc.x, acc.y, acc.z, 0.0f);
-                    q[5] = make_float4(__uint_as_float((uint32_t)s.rng), __uint_as_float((uint32_t)(s.rng >> 32)), 0.0f, 0.0f);
+                    q[4] = make_float4(__uint_as_float((uint32_t)s.rng), __uint_as_float((uint32_t)(s.rng >> 32)), 0.0f, 0.0f);
                     phase = PH_IDLE; start = false; unprunable = false;
                 }
             }
@@ -1783,13 +1808,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             phase = PH_BEGIN;
             if (ended) {
                 if (id_out && p.bounces == 0) *id_out = -1;
-                acc = acc + s.finalColor;                   // m_AccumulationBuffer[pixelIndex] += pixelColor
-                frame++;
-                if (frame < p.n_frames) path_begin(s, p, pixel, p.frame_first + frame);
-                else {
-                    // the unused fourth component carries, from the counting kernels, the node + triangle steps of the pixel's last path
-                    p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, STATS ? (float)path_steps : 0.0f); phase = PH_IDLE;
-                }
+                // pixelColor of this Render: the resolve pass makes "m_AccumulationBuffer[pixelIndex] += pixelColor" of it, frame by
+                // frame.  The fourth component carries, from the counting kernels, the node + triangle steps of the path.
+                p.slots[(size_t)frame * plane + pixel] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, STATS ? (float)path_steps : 0.0f);
+                phase = PH_IDLE;
                 path_steps = 0;
             }
         }
@@ -1833,6 +1855,27 @@ __global__ __launch_bounds__(RT_TREE_BLOCK) void rt_trace_kernel(RtParams p)
     tree_body<MODE, STATS, ORDERED>(p);
 }
 
+// Tree scenes, after the trace launch: "m_AccumulationBuffer[pixelIndex] += pixelColor" (Renderer.cpp:64-66) for the launch's
+// n_frames Renders in frame order -- frame index 1 starts from zero (Renderer.cpp:55-56) -- and the resolve of the last one
+// (Renderer.cpp:68-79).  One lane per pixel of a work unit; the rows bordering a band (halo units) only get their sums.
+__global__ __launch_bounds__(256) void rt_sum_resolve_kernel(RtParams p, uint32_t frame_index, int write_image)
+{
+    const uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    uint32_t pixel;
+    if (unit >= p.n_units || !unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel)) return;
+    const size_t plane = (size_t)p.width * p.height;
+    F3 acc = f3(0.0f, 0.0f, 0.0f);
+    if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
+    float steps = 0.0f;
+    for (uint32_t f = 0; f < p.n_frames; ++f) {
+        const float4 c = p.slots[(size_t)f * plane + pixel];
+        acc = acc + f3(c.x, c.y, c.z);
+        steps = c.w;
+    }
+    p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, steps);
+    if (write_image && unit < p.n_units_main) p.image[pixel] = resolve_px(acc, (float)frame_index, p.use_ace);
+}
+
 // Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
 __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t frame_index)
 {
@@ -1840,8 +1883,6 @@ __global__ __launch_bounds__(256) void rt_resolve_kernel(RtParams p, uint32_t fr
     const uint32_t x = blockIdx.x * RT_TILE + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t band = blockIdx.y * p.band_count + p.band_index;
     const uint32_t y = band * RT_TILE + (wave >> 1) * 8u + (lane >> 3);
-    // the trace kernel that produced this frame has drained the unit queue: zero its heads for the next trace launch
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
     if (x < p.width && y < p.height) {
         const uint32_t pixel = y * p.width + x;
         float4 a = p.accum[pixel];
@@ -1941,18 +1982,22 @@ extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s)
 static void launch_reach(const RtParams& p, int stats, hipStream_t s)
 {
     const unsigned node_blocks = (p.n_nodes + 255u) / 256u;
-    const unsigned cap_blocks = (p.column_cap + 255u) / 256u;                  // the first kernel also clears the column rays' results
-    const unsigned first_grid = (p.ray_slot < 0 && cap_blocks > node_blocks) ? cap_blocks : node_blocks;
-    hipLaunchKernelGGL(rt_column_reach_max_kernel, dim3(first_grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(rt_column_reach_max_kernel, dim3(node_blocks), dim3(256), 0, s, p);
     hipLaunchKernelGGL(rt_column_reach_scan_kernel, dim3(1), dim3(1024), 0, s, p, node_blocks);
     hipLaunchKernelGGL(rt_column_reach_mark_kernel, dim3(node_blocks), dim3(256), 0, s, p, stats);
 }
 
-extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s)
+// `cached`: the queue of undecided (record, 16 rays) pairs on the device still describes this camera, these directions and this
+// tree (it does not depend on anything else), so only the triangle tests on it are repeated.
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int cached, hipStream_t s)
 {
     RtParams q = *p; q.ray_slot = -1;
-    launch_reach(q, stats, s);
-    hipLaunchKernelGGL(rt_column_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+    hipLaunchKernelGGL(rt_column_reset_kernel, dim3((q.column_cap + 255u) / 256u), dim3(256), 0, s, q);
+    if (q.n_refs == 0u) return hipGetLastError();                              // a tree without a triangle: every column ray misses
+    if (!cached) {
+        launch_reach(q, stats, s);
+        hipLaunchKernelGGL(rt_column_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+    }
     hipLaunchKernelGGL(rt_column_exact_kernel, dim3(2048), dim3(256), 0, s, q);
     return hipGetLastError();
 }
@@ -1966,6 +2011,7 @@ extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStr
     for (int family = 0; family < RT_PARK_FAMILIES; ++family) {
         q.ray_slot = family;
         launch_reach(q, stats, s);
+        if (q.n_refs == 0u) continue;                                          // no triangle to test: park_best stays "miss"
         const unsigned rec_blocks = (q.n_refs + 255u) / 256u;
         hipLaunchKernelGGL(rt_park_test_kernel, dim3(rec_blocks < 4096u ? rec_blocks : 4096u), dim3(256), 0, s, q, stats);
     }
@@ -1975,6 +2021,13 @@ extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStr
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s)
 {
     hipLaunchKernelGGL(rt_resolve_kernel, dim3(gx, gy), dim3(256), 0, s, *p, frame_index);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s)
+{
+    const unsigned per_block = 256u / RT_UNIT;
+    hipLaunchKernelGGL(rt_sum_resolve_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p, frame_index, write_image);
     return hipGetLastError();
 }
 

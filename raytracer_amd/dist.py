@@ -45,33 +45,56 @@ def image_tensor(renderer):
     return torch.as_tensor(DeviceArray(renderer.device_image_ptr(), (h, w, 4)), device="cuda:%d" % renderer.device)
 
 
-def sum_accumulation(accum, group=None):
-    """Sample split: sum the per-rank accumulation buffers in place on every rank."""
+def sum_accumulation(accum, dst=0, group=None):
+    """Sample split: the per-rank accumulation buffers summed onto rank `dst` (the only rank that resolves the image).
+    `accum` is (h, w, 4) with an unused fourth component or (n, 3): only the three sums travel (99.5 MB at 4K, not 133)."""
     import torch.distributed as dist
-    if dist.is_initialized():
-        dist.all_reduce(accum, op=dist.ReduceOp.SUM, group=group)
+    if not dist.is_initialized():
+        return accum
+    if accum.shape[-1] == 4:
+        rgb = accum[..., :3].contiguous()
+        dist.reduce(rgb, dst=dst, op=dist.ReduceOp.SUM, group=group)
+        if dist.get_rank(group) == dst:
+            accum[..., :3] = rgb
+    else:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
 
 
+class BandGather:
+    """Tile split: collects every rank's 16-row bands of `image` ((h, w, c) tensor, only this rank's rows valid) on `dst`,
+    once per displayed frame.  Row indices and the send / receive buffers are set up once."""
+
+    def __init__(self, image, rank, world, dst=0, group=None):
+        import torch
+        self.image, self.rank, self.world, self.dst, self.group = image, rank, world, dst, group
+        h = image.shape[0]
+        self.counts = [len(band_rows(h, r, world)) for r in range(world)]
+        most = max(self.counts)
+        dev = image.device
+        self.mine = torch.as_tensor(band_rows(h, rank, world), device=dev, dtype=torch.long)
+        self.send = torch.zeros((most,) + tuple(image.shape[1:]), dtype=image.dtype, device=dev)
+        self.recv = self.rows = None
+        if rank == dst and world > 1:
+            self.recv = [torch.empty_like(self.send) for _ in range(world)]
+            self.rows = [torch.as_tensor(band_rows(h, r, world), device=dev, dtype=torch.long) for r in range(world)]
+
+    def gather(self):
+        """Returns the assembled image on dst (in place: the other ranks' rows are written into `image`), None elsewhere."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.image
+        torch.index_select(self.image, 0, self.mine, out=self.send[: len(self.mine)])
+        dist.gather(self.send, self.recv, dst=self.dst, group=self.group)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world):
+            if r != self.rank:
+                self.image.index_copy_(0, self.rows[r], self.recv[r][: self.counts[r]])
+        return self.image
+
+
 def gather_bands(image, rank, world, dst=0, group=None):
-    """Tile split: collect every rank's bands of `image` ((h, w, c) tensor, only this rank's rows valid) on `dst`.
-    Returns the assembled image on dst, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-    h = image.shape[0]
-    if world == 1:
-        return image
-    counts = [len(band_rows(h, r, world)) for r in range(world)]
-    most = max(counts)
-    mine = torch.as_tensor(band_rows(h, rank, world), device=image.device, dtype=torch.long)
-    send = torch.zeros((most,) + tuple(image.shape[1:]), dtype=image.dtype, device=image.device)
-    send[: len(mine)] = image.index_select(0, mine)
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    out = torch.empty_like(image)
-    for r in range(world):
-        rows = torch.as_tensor(band_rows(h, r, world), device=image.device, dtype=torch.long)
-        out.index_copy_(0, rows, recv[r][: counts[r]])
-    return out
+    """One-off form of BandGather (sets everything up for a single gather)."""
+    return BandGather(image, rank, world, dst, group).gather()

@@ -169,9 +169,10 @@ class Image:
 class Renderer:
     """Renderer (Renderer.h:101-161) running on one MI355X."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
         self._L = lib()
-        self._h = self._L.rt_create(int(device))
+        self._owned = _borrowed is None
+        self._h = self._L.rt_create(int(device)) if self._owned else _borrowed          # a group's context belongs to the group
         if not self._h:
             msg = self._L.rt_last_error(None)
             raise _capi.RtError("rt_create(%d) failed: %s" % (device, msg.decode() if msg else ""))
@@ -181,11 +182,12 @@ class Renderer:
         self.m_frameindex = 1
         self._mesh_ref = None           # the tree object whose mesh is resident (held, so its identity stays unique)
         self.download = True            # Render() ends in Image::SetData (host copy) unless switched off
+        self.pipelined = False          # hand-off one frame late, the copy running beside the next trace (rt_map_image_pipelined)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and getattr(self, "_owned", False):
             self._L.rt_destroy(self._h)
-            self._h = None
+        self._h = None
 
     # ---- reference interface --------------------------------------------------------------------
     def GetSettings(self): return self.m_settings
@@ -209,7 +211,7 @@ class Renderer:
         else:
             self.m_frameindex = 1
         if self.download:
-            self.m_Image.SetData(self.map_image())           # Image.SetData copies, as Walnut::Image::SetData does
+            self.m_Image.SetData(self.map_image(self.pipelined))     # Image.SetData copies, as Walnut::Image::SetData does
 
     # ---- pieces ----------------------------------------------------------------------------------
     def upload(self, scene, camera):
@@ -278,11 +280,12 @@ class Renderer:
         check(self._h, self._L.rt_read_image(self._h, ptr(out)), "rt_read_image")
         return out
 
-    def map_image(self):
+    def map_image(self, pipelined=False):
         """The frame in the library's page-locked staging buffer, as an (h, w, 4) view (valid until the next map_image /
-        OnResize): what a display path hands to Image::SetData without another copy."""
+        OnResize): what a display path hands to Image::SetData without another copy.  `pipelined`: the frame of the
+        previous call, while this one's copy runs beside the next trace."""
         w, h = self._size()
-        p = self._L.rt_map_image(self._h)
+        p = (self._L.rt_map_image_pipelined if pipelined else self._L.rt_map_image)(self._h)
         if not p:
             check(self._h, -1, "rt_map_image")
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(h, w, 4))
@@ -333,3 +336,78 @@ class Renderer:
 
     def device_image_ptr(self):
         return self._L.rt_device_image(self._h)
+
+
+class GroupRenderer:
+    """Renderer (Renderer.h:101-161) over several GPUs of one node from ONE process (rt_group_*): same members as Renderer.
+    split = "tiles": every Render is one frame, traced as 16-row bands dealt round-robin over the devices (single-sample
+    latency); split = "samples": every Render is len(devices) * frames_per_device frames, dealt by frame index (progressive
+    accumulation).  Device 0 of the list assembles the frame.  A device may be listed more than once."""
+
+    def __init__(self, devices, split="tiles", frames_per_device=1):
+        assert split in ("tiles", "samples")
+        self._L = lib()
+        ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._g = self._L.rt_group_create(ids, len(devices))
+        if not self._g:
+            msg = self._L.rt_last_error(None)
+            raise _capi.RtError("rt_group_create(%s) failed: %s" % (list(devices), msg.decode() if msg else ""))
+        self.split, self.frames_per_device = split, int(frames_per_device)
+        self.members = [Renderer(d, _borrowed=self._L.rt_group_ctx(self._g, i)) for i, d in enumerate(devices)]
+        self.m_settings = Settings()
+        self.m_Image = None
+        self.m_frameindex = 1
+        self.download = True
+
+    def __del__(self):
+        if getattr(self, "_g", None):
+            self.members = []
+            self._L.rt_group_destroy(self._g)
+            self._g = None
+
+    def GetSettings(self): return self.m_settings
+    def GetImage(self): return self.m_Image
+    def ResetFrameIndex(self): self.m_frameindex = 1
+    def GetFrameIndex(self): return self.m_frameindex
+
+    def OnResize(self, width, height):
+        if self.m_Image is not None and self.m_Image.GetWidth() == width and self.m_Image.GetHeight() == height:
+            return
+        for m in self.members:
+            m.OnResize(width, height)
+        self.m_Image = Image(width, height)
+        self.ResetFrameIndex()
+
+    def _gcheck(self, rc, what):
+        if rc != _capi.RT_OK:
+            msg = self._L.rt_group_last_error(self._g)
+            raise _capi.RtError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def Render(self, scene, camera):
+        for m in self.members:
+            m.m_settings = self.m_settings
+            m.upload(scene, camera)
+        if self.split == "tiles":
+            frames = 1
+            self._gcheck(self._L.rt_group_render_tiles(self._g, self.m_frameindex, 1), "rt_group_render_tiles")
+        else:
+            frames = len(self.members) * self.frames_per_device
+            self._gcheck(self._L.rt_group_render_samples(self._g, self.m_frameindex, self.frames_per_device), "rt_group_render_samples")
+        self.m_frameindex = self.m_frameindex + frames if self.m_settings.Accumulate else 1
+        if self.download:
+            self.m_Image.SetData(self.members[0].map_image())
+
+    def read_accum(self):
+        """The accumulated radiance of the whole frame: gathered from the owners of the bands (tiles), or the sum over the
+        devices (samples)."""
+        from .dist import band_rows
+        w, h = self.m_Image.GetWidth(), self.m_Image.GetHeight()
+        if self.split == "samples":
+            out = np.empty((h, w, 3), np.float32)
+            self._gcheck(self._L.rt_group_read_accum(self._g, ptr(out)), "rt_group_read_accum")
+            return out
+        out = np.zeros((h, w, 3), np.float32)
+        for i, m in enumerate(self.members):
+            rows = band_rows(h, i, len(self.members))
+            out[rows] = m.read_accum()[rows]
+        return out

@@ -351,6 +351,39 @@ def test_frames_in_one_launch_equal_separate_launches(rt, orc, renderer, mode):
     assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(want["img"]))
 
 
+@pytest.mark.parametrize("mode", [1, 0, 2], ids=["spheres", "mesh", "spheres+mesh"])
+def test_sixteen_frames_per_launch_and_deep_accumulation(rt, orc, renderer, mode):
+    """Launches of 16 Renders (tree scenes: every (pixel, frame) is a path of its own whose radiance goes to that frame's slot,
+    the resolve pass adds the slots in frame order) against the oracle's frame-by-frame sum: 37 frames as 16 + 16 + 5 (one call,
+    split by the library in tree scenes), bit-exact, then on to 133 frames -- accumulation deeper than any other test."""
+    from raytracer_amd import scenes
+    w, h = 128, 72
+    mesh = None if mode == 1 else scenes.displaced_grid(32, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = mode, 5, True, False, True, 1337, 0
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(False); renderer.reset_counters()
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
+    ost = orc.Settings(1, mode, 1, 0, 5)
+    cnt = orc.Counters()
+    for f in range(1, 38):
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, primary_ids=ids if f == 1 else None, counters=cnt)
+    renderer.Render(scene, cam, frames=37)
+    assert renderer.GetFrameIndex() == 38
+    got = dict(ids=renderer.read_primary_ids().ravel(), acc=renderer.read_accum().reshape(-1, 3), img=renderer.GetImage().data.reshape(-1, 4),
+               cnt=renderer.read_counters())
+    assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=cnt))
+    for f in range(38, 134):
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img)
+    renderer.Render(scene, cam, frames=16)
+    renderer.Render(scene, cam, frames=80)
+    assert renderer.GetFrameIndex() == 134
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(acc))
+    assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(img))
+
+
 def test_accumulate_off_and_reset(rt, orc, renderer):
     scene, osc = make_scene(rt, orc)
     w, h = 100, 60
@@ -429,6 +462,65 @@ def test_tile_split_bands_assemble_the_frame(rt, orc, renderer):
         rows = rtd.band_rows(h, rank, world)
         out[rows] = rr.read_accum()[rows]
     assert np.array_equal(bits(out.reshape(-1, 3)), bits(want["acc"]))
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["spheres", "spheres+mesh"])
+def test_tile_split_with_the_3x3_filter(rt, orc, renderer, mode):
+    """The filter (Renderer.cpp:84-124) reads the neighbours' sums, so under a tile split a context also traces and sums the rows
+    bordering its bands: three band contexts with the filter on, three frames (the last two in one launch), assembled image and
+    accumulation against the oracle's filtered frame, bit-exact.  Switching the filter on in the middle of an accumulation is
+    refused until the accumulation restarts."""
+    from raytracer_amd import dist as rtd, scenes, _capi
+    mesh = None if mode == 1 else scenes.displaced_grid(24, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    w, h = 150, 100
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, mode, 5, 3, aa=True)
+    assert_exact(got, want)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    world = 3
+    img = np.zeros((h, w, 4), np.float32); acc = np.zeros((h, w, 3), np.float32)
+    for rank in range(world):
+        rr = rt.Renderer(0)
+        s = rr.GetSettings(); s.SceneMode, s.Bounces, s.AntiAliasing = mode, 5, True
+        rr.OnResize(w, h); rr.set_bands(rank, world)
+        rr.Render(scene, cam); rr.Render(scene, cam, frames=2)
+        rows = rtd.band_rows(h, rank, world)
+        img[rows] = rr.GetImage().data[rows]; acc[rows] = rr.read_accum()[rows]
+        if rank == 1:
+            s.AntiAliasing = False; rr.Render(scene, cam)            # a frame without the bordering rows ...
+            s.AntiAliasing = True
+            with pytest.raises(_capi.RtError):
+                rr.Render(scene, cam)                                # ... and the filter may not read them any more
+            rr.ResetFrameIndex(); rr.Render(scene, cam)              # until the accumulation restarts
+    assert np.array_equal(bits(acc.reshape(-1, 3)), bits(want["acc"]))
+    assert np.array_equal(bits(img.reshape(-1, 4)), bits(want["img"]))
+
+
+def test_pipelined_hand_off_returns_the_previous_frame(rt, orc, renderer):
+    """rt_map_image_pipelined: the copy of frame k runs beside the trace of frame k + 1; each call returns the frame of the call
+    before it (the first its own).  Every returned frame is bit-exact."""
+    scene, osc = make_scene(rt, orc)
+    w, h, n = 200, 120, 5
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    ost = orc.Settings(1, 1, 1, 0, 5)
+    frames = []
+    for f in range(1, n + 1):
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img)
+        frames.append(img.copy())
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.AntiAliasing, st.UseACE_Color, st.Accumulate, st.Seed = 1, 5, False, True, True, 1337
+    renderer.OnResize(w, h); renderer.ResetFrameIndex()
+    renderer.pipelined = True
+    try:
+        for f in range(1, n + 1):
+            renderer.Render(scene, cam)
+            shown = max(f - 1, 1)
+            assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(frames[shown - 1])), "call %d" % f
+            assert np.array_equal(bits(renderer.read_image().reshape(-1, 4)), bits(frames[f - 1]))       # the newest frame, on request
+    finally:
+        renderer.pipelined = False
+    assert np.array_equal(bits(renderer.map_image().reshape(-1, 4)), bits(frames[-1]))
 
 
 def test_sample_split_sum_matches_within_reassociation_tolerance(rt, orc, renderer):
@@ -510,9 +602,9 @@ def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
 
 def test_configs4_and_5_ten_million_triangles_4k(rt, orc, renderer):
     """BASELINE configs[3] and [4] at full size: the 9,999,392-triangle mesh (KD tree of ~16 M nodes, ~7 GB in HBM) at
-    3840x2160, mesh alone (8 bounces) and with the default spheres.  Against the oracle: every 240th row (the oracle needs
-    ~40 s per full frame on 16 cores), ids and accumulation bit-exact in both walk orders, which also covers the column of
-    direction.x == 0.  Over all pixels the two orders are compared with each other (see below)."""
+    3840x2160, mesh alone (8 bounces) and with the default spheres.  Against the oracle: every 16th row of two accumulated frames
+    (the oracle needs ~40 s per full frame on 16 cores), ids and accumulation bit-exact in both walk orders, which also covers
+    the column of direction.x == 0.  Over all pixels the two orders are compared with each other (see below)."""
     import bench
     cfg = bench.CONFIGS[4]
     scene = bench.build_scene(cfg)
@@ -523,20 +615,21 @@ def test_configs4_and_5_ten_million_triangles_4k(rt, orc, renderer):
     w, h = cfg["w"], cfg["h"]
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
-    rows = np.arange(0, h, 240)
+    rows = np.arange(0, h, 16)
     st = renderer.GetSettings()
     renderer.download = False
     try:
         for mode, bounces in ((0, 8), (2, 8)):
             st.SceneMode, st.Bounces, st.AntiAliasing, st.Accumulate, st.UseACE_Color, st.Seed = mode, bounces, False, True, True, 1337
             acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.full(h * w, -7, np.int32)
-            osc.render_frame(orc.Settings(1, mode, 1, 0, bounces), cam.GetPosition(), dirs, w, h, 1, acc, img, primary_ids=ids,
-                             nthreads=16, row_step=240)
+            for f in (1, 2):
+                osc.render_frame(orc.Settings(1, mode, 1, 0, bounces), cam.GetPosition(), dirs, w, h, f, acc, img,
+                                 primary_ids=ids if f == 1 else None, nthreads=16, row_step=16)
             full = {}
             for order in (REF_ORDER, F2B_ORDER):
                 st.TraversalOrder = order
                 renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
-                renderer.Render(scene, cam)
+                renderer.Render(scene, cam, frames=2)
                 full[order] = (renderer.read_primary_ids().copy(), renderer.read_accum().copy())
                 assert np.array_equal(full[order][0][rows], ids.reshape(h, w)[rows]), "mode %d order %d: primary ids" % (mode, order)
                 assert np.array_equal(bits(full[order][1][rows]), bits(acc.reshape(h, w, 3)[rows])), "mode %d order %d: accumulation" % (mode, order)
