@@ -180,6 +180,20 @@ int rt_render(rt_ctx*, uint32_t frame_index);
    launch.  Tree scenes: launches of up to 16 frames whose (pixel, frame) paths are drawn independently, so the lanes of the
    chip stay busy across the frames -- several times the rate of single Renders. */
 int rt_render_frames(rt_ctx*, uint32_t frame_index, uint32_t n);
+/* No counterpart in the reference.  One Render of a SPHERE scene (rt_render with scene_mode RT_SCENE_SPHERES) for callers that
+   cannot allocate where they render: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It
+   needs no context and calls no hipMalloc / hipFree / hipHostMalloc: the ray directions and the device copies of the scene
+   tables, which rt_render keeps in buffers of the context, live in one static device array of the library (32 MiB + 2 KiB on
+   each GPU, held until the process ends), and the caller passes the rest: d_accum and d_image are DEVICE buffers of
+   width*height float4 (rgb + unused w; RGBA32F) on `device`; frame_index == 1 starts the sum from zero, any other index adds to
+   what d_accum holds.  Same kernels as rt_render, so the same bits.  Asynchronous on `hip_stream` (a hipStream_t, NULL = the
+   default stream).  Fixed limits, RT_E_LIMIT beyond them: width*height <= 2,097,152 (1920x1080 fits), 32 spheres, 32 materials.
+   Every call on a GPU uses that GPU's one array: calls that overlap in time on one GPU race; calls ordered by a stream or by
+   events do not, and nothing has to survive in the array from one call to the next.  Errors: rt_last_error(NULL). */
+int rt_render_spheres_noalloc(int device, void* hip_stream, const rt_sphere* spheres, uint32_t n_spheres,
+                              const rt_material* materials, uint32_t n_materials, const rt_settings* settings,
+                              const float cam_pos[3], const float inv_proj[16], const float inv_view[16],
+                              uint32_t width, uint32_t height, uint32_t frame_index, float* d_accum, float* d_image);
 /* Resolve only (Renderer.cpp:68-79, 84-124): rebuild the image from the accumulation buffer as if
    `frame_index` frames had been summed (used after a cross-GPU sum of accumulation buffers). */
 int rt_resolve(rt_ctx*, uint32_t frame_index);

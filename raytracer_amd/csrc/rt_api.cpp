@@ -28,6 +28,7 @@ extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_in
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
+extern "C" hipError_t rt_static_setup(int device);               // rt_static.hip: per-device address of its static working memory
 
 namespace {
 
@@ -317,6 +318,7 @@ rt_ctx* rt_create(int device_id)
         rt_destroy(c); return nullptr;
     }
     c->n_cus = prop.multiProcessorCount;
+    (void)rt_static_setup(device_id);      // set-up of rt_render_spheres_noalloc on this device (it reports a failure itself when called)
     if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) { c->park_min_nodes = (uint32_t)v; c->park_min_forced = true; } }
     return c;
 }

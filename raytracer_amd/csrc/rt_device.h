@@ -80,6 +80,11 @@
 #define RT_LDS_SPHERES 128         // scenes with at most this many spheres and materials keep them in LDS for the per-lane
 #define RT_LDS_MATERIALS 128       // lookups of the closest hit (a few KB per workgroup); larger scenes read them from HBM
 
+// rt_render_spheres_noalloc: fixed limits of the one entry point whose working memory is a static device array
+#define RT_STATIC_MAX_PIXELS (1u << 21)      // 2,097,152 >= 1920 x 1080; one float4 ray direction each = 32 MiB per GPU
+#define RT_STATIC_MAX_SPHERES 32             // = RT_INLINE_SPHERES: the sphere loop reads them from the kernel arguments
+#define RT_STATIC_MAX_MATERIALS 32
+
 #define RT_LEAF_INTERIOR (-1)      // RtNode.leaf_first: not a leaf
 #define RT_LEAF_EMPTY    (-2)      // a leaf that owns no triangle
 
