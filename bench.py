@@ -249,6 +249,7 @@ def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=Non
 def with_d2h(r, torch, steps):
     """ms per Render including the frame's way to host memory, as the drop-in Renderer::Render ends (Renderer.cpp:134)."""
     out = {}
+    r.sync(); r.set_stream(None)                     # the library's own streams: the copy stream then runs beside the render stream
     for name, pipelined in (("ms_per_step_map_image", False), ("ms_per_step_map_image_pipelined", True)):
         r.reset_accum()
         for f in range(1, 4):
@@ -306,6 +307,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the tree configurations 3 and 4 of the default one-GPU run")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--profile", default="", choices=["", "single", "throughput"],
+                    help="for profiler passes: only one-Render-per-launch steps, or only launches of 16 Renders (timed launches of one kind "
+                         "under the trace kernel's name; no hand-off, no other configurations)")
     ap.add_argument("--order", default="auto", choices=sorted(ORDERS),
                     help="KD tree walk order of mesh scenes (auto = front to back on a KD tree)")
     args = ap.parse_args()
@@ -379,9 +383,10 @@ def main():
     r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
     torch.cuda.synchronize(); barrier()
 
+    per_launch = FRAMES_PER_LAUNCH if args.profile == "throughput" else 1
     t0 = time.perf_counter()
-    for f in frames:                                 # every rank starts from a zeroed buffer (rt_reset_accum)
-        r.render_only(f)
+    for f in frames[::per_launch]:                   # every rank starts from a zeroed buffer (rt_reset_accum)
+        r.render_only(f, per_launch)
         if bands is not None:
             bands.gather()                           # the displayed frame, assembled on rank 0
     if use_dist and not tile_split:
@@ -411,7 +416,9 @@ def main():
                        "rays_per_frame": rays_total / (K if tile_split else K * world), "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
-        if world == 1 and not use_dist:
+        if args.profile:
+            out["profile"] = args.profile + (": %d Renders per launch in the timed region" % per_launch)
+        if world == 1 and not use_dist and not args.profile:
             out["throughput_mode"] = throughput_mode(r, cfg, torch, max(1, K // FRAMES_PER_LAUNCH), rays_total / K,
                                                      roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))
             out["with_d2h"] = with_d2h(r, torch, min(K, 32))
@@ -420,7 +427,7 @@ def main():
             if cfg["mesh"] and cfg["mesh"][1] > 1000:
                 n = 1                                                    # 10 M triangles at 4K: one frame of every 64th row
             out["cpu_baseline"] = cpu_baseline(cfg, scene, cam, n)
-        if world == 1 and not use_dist and args.config == 2 and not args.no_other_configs:
+        if world == 1 and not use_dist and args.config == 2 and not args.no_other_configs and not args.profile:
             # the tree configurations in the same run, so that one driver-timed command covers them (one Render per launch and
             # throughput mode each; counters, event times and rooflines as for the main configuration)
             del r

@@ -118,7 +118,11 @@ struct rt_ctx {
     DevBuf<uint32_t> d_park_count, d_park_flags, d_park_list;
     DevBuf<int32_t> d_park_info;
     DevBuf<float4> d_park_paths;
-    DevBuf<unsigned long long> d_park_best;
+    DevBuf<unsigned long long> d_park_best, d_park_keys;
+    DevBuf<float4> d_park_boxes;
+    DevBuf<uint2> d_park_queue;
+    DevBuf<uint32_t> d_park_queue_count;
+    static const uint32_t kParkQueueCap = 1u << 22;        // pairs per family (32 MB); beyond it the filter tests in place
     DevBuf<unsigned long long> d_column_best;
     DevBuf<unsigned char> d_reached;
     DevBuf<uint32_t> d_rec_leaf;                        // per leaf record: the node index of its leaf (4 bytes instead of the record's 48)
@@ -128,10 +132,12 @@ struct rt_ctx {
 
     int n_cus = 0;
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
-    float root_center[3] = {0.0f, 0.0f, 0.0f}, root_reach = 0.0f;    // see RtParams
+    float root_center[3] = {0.0f, 0.0f, 0.0f};                       // see RtParams
+    float tie_box[3] = {0.0f, 0.0f, 0.0f}, tie_ulp = 0.0f, tie_rel = 0.0f, tie_abs = 0.0f;
     bool park_min_forced = false;
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
+    bool kd_listing = false;             // ... and (on a sample of the triangles) every triangle is listed in each leaf whose box it overlaps
 
     rt_kernel_time ktime{0, 0.0, 0.0, 0.0, 0};
 };
@@ -164,6 +170,7 @@ void grid_for(const rt_ctx* c, unsigned& gx, unsigned& gy)
     gy = bands > c->band_index ? (bands - c->band_index + c->band_count - 1) / c->band_count : 0;
 }
 
+constexpr float kAutoMaxTieRel = 1.0f / 512.0f;
 constexpr unsigned kMaxBlocksPerCu = 8;      // 8 workgroups of 4 waves = the 32 waves a CU can hold
 
 void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames)
@@ -204,10 +211,12 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.column_queue_cap = rt_ctx::kColumnQueueCap;
     p.park_count = c->d_park_count.ptr; p.park_flags = c->d_park_flags.ptr; p.park_paths = c->d_park_paths.ptr; p.park_best = c->d_park_best.ptr;
     p.resume_count = c->d_park_count.ptr; p.resume_paths = c->d_park_paths.ptr; p.park_list = c->d_park_list.ptr; p.park_info = c->d_park_info.ptr;
+    p.park_keys = c->d_park_keys.ptr; p.park_boxes = c->d_park_boxes.ptr; p.park_queue = c->d_park_queue.ptr;
+    p.park_queue_count = c->d_park_queue_count.ptr; p.park_queue_cap = rt_ctx::kParkQueueCap;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
     p.slice_leave = c->n_nodes >= RT_LARGE_TREE ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
-    for (int a = 0; a < 3; ++a) p.root_center[a] = c->root_center[a];
-    p.root_reach = c->root_reach;
+    for (int a = 0; a < 3; ++a) { p.root_center[a] = c->root_center[a]; p.tie_box[a] = c->tie_box[a]; }
+    p.tie_ulp = c->tie_ulp; p.tie_rel = c->tie_rel; p.tie_abs = c->tie_abs;
 }
 
 // Every material index a kernel can read must be in range: the kernels do not check.
@@ -303,7 +312,9 @@ rt_ctx* rt_create(int device_id)
         hipMemset(c->d_wave_clock.ptr, 0, c->d_wave_clock.count * sizeof(unsigned long long)) != hipSuccess ||
         c->d_park_count.resize(2) != hipSuccess || hipMemset(c->d_park_count.ptr, 0, 8) != hipSuccess ||
         c->d_park_flags.resize(RT_PARK_SLOTS) != hipSuccess || hipMemset(c->d_park_flags.ptr, 0, 4 * RT_PARK_SLOTS) != hipSuccess ||
-        c->d_park_list.resize(RT_PARK_FAMILIES * RT_PARK_SLOTS) != hipSuccess || c->d_park_info.resize(3 * RT_PARK_FAMILIES) != hipSuccess ||
+        c->d_park_list.resize(RT_PARK_FAMILIES * RT_PARK_SLOTS) != hipSuccess || c->d_park_keys.resize(RT_PARK_FAMILIES * RT_PARK_SLOTS) != hipSuccess ||
+        c->d_park_boxes.resize((size_t)RT_PARK_FAMILIES * 2 * (RT_PARK_BOXES + 1)) != hipSuccess ||
+        c->d_park_queue.resize((size_t)RT_PARK_FAMILIES * rt_ctx::kParkQueueCap) != hipSuccess || c->d_park_queue_count.resize(RT_PARK_FAMILIES) != hipSuccess || c->d_park_info.resize(3 * RT_PARK_FAMILIES) != hipSuccess ||
         c->d_park_paths.resize(2 * (size_t)RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
@@ -332,7 +343,8 @@ void rt_destroy(rt_ctx* c)
     c->d_trishade.release(); c->d_accum.release(); c->d_image.release(); c->d_sphere_mat.release();
     c->d_dirs.release(); c->d_ids.release(); c->d_counters.release(); c->d_wave_clock.release(); c->d_column_stats.release(); c->d_work_heads.release();
     c->d_park_count.release(); c->d_park_flags.release(); c->d_park_paths.release(); c->d_park_best.release();
-    c->d_park_list.release(); c->d_park_info.release();
+    c->d_park_list.release(); c->d_park_info.release(); c->d_park_keys.release(); c->d_park_boxes.release();
+    c->d_park_queue.release(); c->d_park_queue_count.release();
     c->d_column_count.release(); c->d_column_pixels.release(); c->d_column_flags.release(); c->d_column_best.release(); c->d_reached.release(); c->d_rec_leaf.release();
     c->d_column_block.release(); c->d_column_queue_count.release(); c->d_column_dirs.release(); c->d_column_boxes.release(); c->d_column_queue.release();
     for (int i = 0; i < rt_ctx::EV_RING; ++i) {
@@ -635,23 +647,80 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
         HIP_TRY(c, hipMemcpy(c->d_rec_leaf.ptr, rec_leaf.data(), rec_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     {
-        float reach[3] = {0.0f, 0.0f, 0.0f};
+        // the near-tie distance of the front-to-back walk (RtParams::tie_*)
+        double reach[3] = {0.0, 0.0, 0.0}, mag[3] = {0.0, 0.0, 0.0};
         for (uint32_t n = 0; n < N; ++n)
             for (int a = 0; a < 3; ++a) {
-                const float d = fabsf(kd->center[3 * (size_t)n + a] - kd->center[a]) + fabsf(kd->extent[3 * (size_t)n + a]);
-                if (d > reach[a]) reach[a] = d;
+                const double ce = kd->center[3 * (size_t)n + a], ex = std::fabs((double)kd->extent[3 * (size_t)n + a]);
+                reach[a] = std::max(reach[a], std::fabs(ce - (double)kd->center[a]) + ex);
+                mag[a] = std::max(mag[a], std::fabs(ce) + ex);
             }
-        for (int a = 0; a < 3; ++a) c->root_center[a] = kd->center[a];
-        c->root_reach = reach[0] + reach[1] + reach[2];
+        double k_max = 0.0, e_max = 0.0;                   // max |e1|_1 |e2|_1 and the longest edge component over the triangles
+        for (uint32_t t = 0; t < c->n_tris; ++t) {
+            const uint32_t* ix = &c->h_tris[3 * (size_t)t];
+            const float* v0 = &c->h_verts[3 * (size_t)ix[0]]; const float* v1 = &c->h_verts[3 * (size_t)ix[1]]; const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
+            double n1 = 0.0, n2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                const double d1 = std::fabs((double)v1[a] - v0[a]), d2 = std::fabs((double)v2[a] - v0[a]);
+                n1 += d1; n2 += d2; e_max = std::max(e_max, std::max(d1, d2));
+            }
+            k_max = std::max(k_max, n1 * n2);
+        }
+        const double u = 5.9604644775390625e-8, K = k_max / 1e-5;
+        double scale = 1.0;                                // RT_TIE_SCALE=<x> scales the distance (experiments: below 1 the guarantee is void)
+        if (const char* e = getenv("RT_TIE_SCALE")) { const double v = atof(e); if (v > 0.0) scale = v; }
+        for (int a = 0; a < 3; ++a) { c->root_center[a] = kd->center[a]; c->tie_box[a] = (float)((reach[a] + mag[a]) * 1.0000002); }
+        c->tie_ulp = (float)(8.0 * u * scale);
+        c->tie_rel = (float)(2.0 * u * (48.0 * K + 4.0) * scale);
+        c->tie_abs = (float)(112.0 * u * K * e_max * scale);
     }
-    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->column_cache = false;
+    // The front-to-back walk needs every triangle in each leaf whose box it overlaps (the reference builder lists them so,
+    // KDTreeCPU.cpp:548-597).  Checked on up to 65,536 evenly spaced triangles: down from the root into every child whose box,
+    // shrunk by a rounding margin, the triangle's own box overlaps; the leaves reached must list it.
+    bool listing = partition;
+    if (listing) {
+        const uint32_t step = c->n_tris > 65536u ? c->n_tris / 65536u : 1u;
+        std::vector<uint32_t> todo;
+        for (uint32_t t = 0; t < c->n_tris && listing; t += step) {
+            const uint32_t* ix = &c->h_tris[3 * (size_t)t];
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; ++a) {
+                const float x0 = c->h_verts[3 * (size_t)ix[0] + a], x1 = c->h_verts[3 * (size_t)ix[1] + a], x2 = c->h_verts[3 * (size_t)ix[2] + a];
+                lo[a] = std::min(x0, std::min(x1, x2)); hi[a] = std::max(x0, std::max(x1, x2));
+            }
+            todo.clear(); todo.push_back(0);
+            while (!todo.empty() && listing) {
+                const uint32_t n = todo.back(); todo.pop_back();
+                bool inside = true;
+                for (int a = 0; a < 3 && inside; ++a) {
+                    const float ce = kd->center[3 * (size_t)n + a], ex = kd->extent[3 * (size_t)n + a];
+                    const float margin = 1e-5f * (std::fabs(ce) + ex) + 1e-30f;
+                    inside = lo[a] < ce + ex - margin && hi[a] > ce - ex + margin;
+                }
+                if (!inside) continue;
+                const int32_t l = kd->left[n], r = kd->right[n];
+                if (l < 0 && r < 0) {
+                    bool listed = false;
+                    for (int32_t i = 0; i < kd->count[n] && !listed; ++i) listed = (uint32_t)kd->leaf_idx[kd->first[n] + i] == t;
+                    if (!listed) listing = false;
+                } else {
+                    if (l >= 0) todo.push_back((uint32_t)l);
+                    if (r >= 0) todo.push_back((uint32_t)r);
+                }
+            }
+        }
+    }
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false;
     return RT_OK;
 }
 
 int rt_traversal_in_use(const rt_ctx* c)
 {
     if (!c) return RT_E_ARG;
-    const bool ordered = c->settings.traversal == RT_ORDER_FRONT_TO_BACK || (c->settings.traversal == RT_ORDER_AUTO && c->kd_partition);
+    // AUTO walks front to back where that is both exact and cheap: a KD tree with complete leaf lists, and a mesh whose near-tie
+    // distance (RtParams::tie_rel, it grows with the square of the largest triangle) is small enough for repeats to stay rare
+    const bool ordered = c->settings.traversal == RT_ORDER_FRONT_TO_BACK ||
+                         (c->settings.traversal == RT_ORDER_AUTO && c->kd_partition && c->kd_listing && c->tie_rel <= kAutoMaxTieRel);
     return ordered ? RT_ORDER_FRONT_TO_BACK : RT_ORDER_REFERENCE;
 }
 

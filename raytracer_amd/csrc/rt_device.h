@@ -27,7 +27,7 @@
 #define RT_SPHERE_POOL_WORDS 20    // 32-bit words of a sphere-scene path
 #define RT_PARK_SLOTS 16384        // bounce rays the tree cannot prune that one round can hand to whole-chip kernels (a launch of 16 frames of
                                    // spheres + mesh at 4K parks about 5,600)
-#define RT_PARK_CHUNK 1024         // ... of which this many wait in LDS at a time while the records stream past
+#define RT_PARK_BOXES (RT_PARK_SLOTS / 16 + RT_PARK_SLOTS / 64 + RT_PARK_SLOTS / 256)   // boxes of 16, 64 and 256 sorted rays of a family (two float4 each)
 #define RT_PARK_FAMILIES 2         // ... grouped by (origin.x, sign of the zero): rays of a family visit the same nodes
 #define RT_PARK_MIN_NODES (1u << 18)   // ... in trees at least this large by default (in smaller ones the wave that owns the ray walks it)
 #define RT_PARK_MIN_NODES_MIXED (1u << 12)   // ... and with spheres and mesh together, where such rays come by the hundred
@@ -37,17 +37,7 @@
 #ifndef RT_NEAR_TIES
 #define RT_NEAR_TIES 1             /* 0 compiles the near-tie test and the repeat walk out (A/B measurements) */
 #endif
-/* Near ties of the front-to-back walk.  A box's entry distance is (centre - origin) * (1 / direction) -/+ extent * (1 / direction):
-   about three roundings of magnitude |plane - origin| * |1 / direction component|, which the kernel bounds per ray by
-   reach * steep (an overestimate by the sum over the axes); a hit distance carries the roundings of the triangle test, taken
-   as RT_TIE_REL * t.  Two different triangles hit within RT_TIE_ULPS * 2^-23 * reach * steep + RT_TIE_REL * t of each other are
-   a near tie. */
-#ifndef RT_TIE_ULPS
-#define RT_TIE_ULPS 1.0f
-#endif
-#ifndef RT_TIE_REL
-#define RT_TIE_REL 1.9073486328125e-6f   /* 2^-19 */
-#endif
+/* Near ties of the front-to-back walk: see RtParams::tie_* for the distance within which two different triangles count as one. */
 #ifndef RT_SLICE_LEAVE
 #define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left ... */
 #endif
@@ -172,12 +162,31 @@ struct RtParams {
     const float4*   resume_paths;
     unsigned long long* park_best;           // per slot of that list: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
     uint32_t* park_flags;                    // per slot of that list, bit 0: no whole-chip result (a decision depended on t, or a third family)
-    uint32_t* park_list;                     // RT_PARK_FAMILIES x RT_PARK_SLOTS: the slots of each family
+    uint32_t* park_list;                     // RT_PARK_FAMILIES x RT_PARK_SLOTS: the slots of each family, sorted by (pixel, frame)
+    unsigned long long* park_keys;           // ... and the sort keys they are sorted by: pixel << 19 | frame << 14 | slot
+    float4*   park_boxes;                    // per family: (RT_PARK_BOXES + 1) x 2 float4, boxes of the origins / directions of 16, 64, 256 sorted
+                                             // rays, and last of all its rays
+    uint2*    park_queue;                    // per family: (leaf record, 16-ray box) pairs that need the real triangle test
+    uint32_t* park_queue_count;              // per family
+    uint32_t  park_queue_cap;
     int32_t*  park_info;                     // per family: [f] representative slot (-1 = none), [2 + f] size, [4 + f] bit 0: visited set depends on t
     uint32_t  park_min_nodes;                // park only in trees with at least this many nodes
     uint32_t  slice_leave;                   // a walk slice of the trace kernel ends when this many quarters of its walkers are left
-    float     root_center[3];                // centre of the tree's root box and the sum over the axes of the largest
-    float     root_reach;                    // |node centre - root centre| + node half-extent: bounds |box plane - point in the tree|
+    float     root_center[3];                // centre of the tree's root box
+    // Near ties of the front-to-back walk.  Its result is KDTreeCPU::intersect's whenever no two different triangles are hit within
+    // 2 eps(t) of each other, eps(t) = e_box + e_tri(t) bounding how far a box's computed entry distance can lie behind the computed
+    // hit distance of a triangle whose hit point the box contains (proof in the design notes: a subtree is pruned only beyond
+    // t + 2 eps, so neither walk can have missed the other's answer).  Rays that do see two such hits are walked again in the
+    // reference's order.
+    //   e_box    = 4 u max_a (|origin_a - root_centre_a| + tie_box[a]) |1 / direction_a|, u = 2^-24: the slab test's four
+    //              roundings per plane, plus the two of the builder's centre / half-extent form of the box; tie_box[a] =
+    //              max over the nodes of (|centre_a - root_centre_a| + extent_a) + max over the nodes of (|centre_a| + extent_a)
+    //   e_tri(t) = t u (48 K + 4) + 56 u K e_max: first-order rounding analysis of Intersections::triIntersect with a factor
+    //              of two to spare, for ANY triangle of the mesh (also one never tested): K = max |e1|_1 |e2|_1 / 1e-5 -- the
+    //              test rejects |determinant| < 1e-5, which caps the conditioning -- and e_max the longest edge component
+    // tie_ulp = 8 u, tie_rel = 2 u (48 K + 4), tie_abs = 112 u K e_max hold the factor 2.
+    float     tie_box[3];
+    float     tie_ulp, tie_rel, tie_abs;
     int32_t   ray_slot;                      // which rays the reach / test kernels serve: -1 = the column rays, else a family of parked rays
     uint32_t  resume;                        // trace kernel: 0 = draw units; 1 = continue the paths of the resume list (may park again);
                                              // 2 = the same, but rays the tree cannot prune are walked by their wave

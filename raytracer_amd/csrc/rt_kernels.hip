@@ -434,7 +434,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
         if (valid) { n0 = nodes[2 * (size_t)j]; n1 = nodes[2 * (size_t)j + 1]; }
         float tNear;
         const bool box = slab_test(n0, n1, O, invD, tNear);
-        const bool descend = valid && box && !(tNear > (ORDERED && RT_NEAR_TIES ? t_prune + (tol + RT_TIE_REL * t_prune) : t_prune));
+        const bool descend = valid && box && !(tNear > (ORDERED && RT_NEAR_TIES ? t_prune + (tol + p.tie_rel * t_prune) : t_prune));
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
         // ends of the rejected subtrees up to and including this lane's node; a node that is not rejected contributes nothing,
@@ -471,7 +471,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
                 float tt, u, v;
                 if (tri_test(r0, r1, r2, O, D, tt, u, v) && counts) {
                     const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
-                    if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + RT_TIE_REL * fminf(tt, t)) near_tie = true;
+                    if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + p.tie_rel * fminf(tt, t)) near_tie = true;
                     if (tt < t || (tt == t && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
                 }
                 if (group_ends != 0u) open = false;
@@ -492,7 +492,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
         if (ot < t || (ot == t && orec < rec_best)) { t = ot; rec_best = orec; tri = otri; hu = ou; hv = ov; }
     }
     // a lane whose own closest hit is another triangle within that distance of the wave's: a near tie across lanes
-    if (ORDERED && RT_NEAR_TIES && tri_own != tri && fabsf(t_own - t) <= tol + RT_TIE_REL * fminf(t_own, t)) near_tie = true;
+    if (ORDERED && RT_NEAR_TIES && tri_own != tri && fabsf(t_own - t) <= tol + p.tie_rel * fminf(t_own, t)) near_tie = true;
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
     best_rec = rec_best;
     return __ballot(near_tie) != 0ull;
@@ -1054,8 +1054,10 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
 // Parked rays (direction.x == 0, see tree_body).  With an infinite inverse in x the slab test hits every box on one side of
 // origin.x and misses every box on the other, whatever y and z are, so all parked rays with the same origin.x and the same
 // sign of the zero visit the same nodes: a family.  (A glass sphere centred on the camera's x turns the whole centre column
-// of primary rays into such bounce rays: same plane, hundreds per frame.)  This kernel sorts the slots of the list being
+// of primary rays into such bounce rays: same plane, hundreds per frame.)  This kernel deals the slots of the list being
 // resolved into at most RT_PARK_FAMILIES families; further families get no whole-chip result and are walked by their wave.
+// Each member gets a sort key (pixel, frame, slot): neighbouring pixels -- and the same pixel in the other frames of a launch,
+// whose path up to a refraction is the same -- have neighbouring or equal rays, which is what the boxes below need.
 __global__ __launch_bounds__(1024) void rt_park_group_kernel(RtParams p)
 {
     __shared__ uint32_t key0[2], rep1, sizes[RT_PARK_FAMILIES];
@@ -1063,6 +1065,7 @@ __global__ __launch_bounds__(1024) void rt_park_group_kernel(RtParams p)
     const uint32_t tid = threadIdx.x;
     if (tid == 0) { rep1 = 0xFFFFFFFFu; sizes[0] = sizes[1] = 0u; }
     if (tid < 3 * RT_PARK_FAMILIES) p.park_info[tid] = tid < RT_PARK_FAMILIES ? -1 : 0;
+    if (tid < RT_PARK_FAMILIES) p.park_queue_count[tid] = 0u;
     if (n == 0u) return;
     if (tid == 0) { key0[0] = __float_as_uint(p.resume_paths[0].x); key0[1] = __float_as_uint(p.resume_paths[1].x); }
     __syncthreads();
@@ -1080,7 +1083,11 @@ __global__ __launch_bounds__(1024) void rt_park_group_kernel(RtParams p)
         if (ox == key0[0] && dx == key0[1]) fam = 0;
         else if (rep1 != 0xFFFFFFFFu && ox == k1o && dx == k1d) fam = 1;
         p.park_flags[sl] = fam < 0 ? 1u : 0u;
-        if (fam >= 0) p.park_list[fam * RT_PARK_SLOTS + atomicAdd(&sizes[fam], 1u)] = sl;
+        if (fam >= 0) {
+            const uint32_t pixel = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl + 2].w), frame = __float_as_uint(p.resume_paths[RT_PARK_WORDS * sl + 3].w);
+            static_assert(RT_PARK_SLOTS <= (1 << 14) && RT_MAX_LAUNCH_FRAMES <= (1 << 5), "sort key: pixel << 19 | frame << 14 | slot");
+            p.park_keys[fam * RT_PARK_SLOTS + atomicAdd(&sizes[fam], 1u)] = ((unsigned long long)pixel << 19) | ((unsigned long long)(frame & 31u) << 14) | sl;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -1089,56 +1096,205 @@ __global__ __launch_bounds__(1024) void rt_park_group_kernel(RtParams p)
     }
 }
 
-// Every ray of a family against every record of the leaves the family visits: the real triangle test, min (t, record index)
-// per ray.  A fixed grid strides over the records (each read once); the family's rays wait in LDS.
-__global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p, int stats)
+// One workgroup per family: its keys sorted (bitonic, in place), the slot list in that order, and the boxes of the origins and
+// directions of every 16, 64 and 256 consecutive rays: { min oy, max oy, min oz, max oz } { min dy, max dy, min dz, max dz }
+// (origin.x and the zero direction.x are the family's).  A box holding a non-finite or huge component is stored with a NaN
+// first: the filter then proves nothing with it.
+__global__ __launch_bounds__(1024) void rt_park_sort_kernel(RtParams p)
 {
-    __shared__ float4 ray_o[RT_PARK_CHUNK], ray_d[RT_PARK_CHUNK];       // origin + slot, direction
+    const uint32_t fam = blockIdx.x, tid = threadIdx.x;
+    if (p.park_info[fam] < 0) return;
+    const uint32_t n = (uint32_t)p.park_info[RT_PARK_FAMILIES + fam];
+    unsigned long long* keys = p.park_keys + fam * RT_PARK_SLOTS;
+    uint32_t* list = p.park_list + fam * RT_PARK_SLOTS;
+    uint32_t N = 1; while (N < n) N <<= 1;
+    for (uint32_t i = n + tid; i < N; i += 1024u) keys[i] = ~0ull;
+    __syncthreads();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t t = tid; t < (N >> 1); t += 1024u) {
+                const uint32_t i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), l = i | j;     // i has bit j clear
+                const unsigned long long a = keys[i], b = keys[l];
+                const bool up = (i & k) == 0u;
+                if ((a > b) == up) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    for (uint32_t i = tid; i < n; i += 1024u) list[i] = (uint32_t)(keys[i] & (RT_PARK_SLOTS - 1u));
+    __syncthreads();
+    const uint32_t n16 = (n + 15u) / 16u, n64 = (n + 63u) / 64u, n256 = (n + 255u) / 256u;
+    float4* box16 = p.park_boxes + (size_t)fam * 2u * (RT_PARK_BOXES + 1u);
+    float4* box64 = box16 + 2u * (RT_PARK_SLOTS / 16u);
+    float4* box256 = box64 + 2u * (RT_PARK_SLOTS / 64u);
+    for (uint32_t i = tid; i < n16 + n64 + n256; i += 1024u) {
+        uint32_t first, last; float4* out;
+        if (i < n16) { first = i * 16u; last = first + 16u; out = box16 + 2u * i; }
+        else if (i < n16 + n64) { first = (i - n16) * 64u; last = first + 64u; out = box64 + 2u * (i - n16); }
+        else { first = (i - n16 - n64) * 256u; last = first + 256u; out = box256 + 2u * (i - n16 - n64); }
+        if (last > n) last = n;
+        const float inf = __builtin_inff();
+        float lo[4] = {inf, inf, inf, inf}, hi[4] = {-inf, -inf, -inf, -inf};
+        bool usable = true;
+        for (uint32_t r = first; r < last; ++r) {
+            const float4 o4 = p.resume_paths[RT_PARK_WORDS * list[r]], d4 = p.resume_paths[RT_PARK_WORDS * list[r] + 1];
+            const float c[4] = {o4.y, o4.z, d4.y, d4.z};
+            for (int a = 0; a < 4; ++a) {
+                usable = usable && fabsf(c[a]) < 1e9f;                        // false for NaN and infinities too
+                lo[a] = c[a] < lo[a] ? c[a] : lo[a]; hi[a] = c[a] > hi[a] ? c[a] : hi[a];
+            }
+        }
+        out[0] = usable ? make_float4(lo[0], hi[0], lo[1], hi[1]) : make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+        out[1] = make_float4(lo[2], hi[2], lo[3], hi[3]);
+    }
+    __syncthreads();
+    if (tid == 0) {                                                     // the box of the whole family, from its 256-ray boxes
+        float4 f0 = box256[0], f1 = box256[1];
+        for (uint32_t i = 1; i < n256; ++i) {
+            const float4 g0 = box256[2u * i], g1 = box256[2u * i + 1u];
+            if (!(g0.x == g0.x)) f0.x = g0.x;                           // a NaN stays
+            f0.x = g0.x < f0.x ? g0.x : f0.x; f0.y = g0.y > f0.y ? g0.y : f0.y; f0.z = g0.z < f0.z ? g0.z : f0.z; f0.w = g0.w > f0.w ? g0.w : f0.w;
+            f1.x = g1.x < f1.x ? g1.x : f1.x; f1.y = g1.y > f1.y ? g1.y : f1.y; f1.z = g1.z < f1.z ? g1.z : f1.z; f1.w = g1.w > f1.w ? g1.w : f1.w;
+        }
+        box16[2u * RT_PARK_BOXES] = f0; box16[2u * RT_PARK_BOXES + 1u] = f1;
+    }
+}
+
+// True when tri_test fails for EVERY ray with origin (ox, [b0.x, b0.y], [b0.z, b0.w]) and direction (+-0, [b1.x, b1.y], [b1.z, b1.w]):
+// interval arithmetic over the very operations of tri_test, as column_box_rejects, now with the origin a box as well.  With
+// direction.x == +-0: h.y = D.z*e2.x - e2.z*D.x = D.z*e2.x, h.z = D.x*e2.y - e2.x*D.y = -(e2.x*D.y) and D.x*q.x + D.y*q.y = D.y*q.y
+// exactly (a product with the zero is a zero, and x - 0 = x, 0 - x = -x, 0 + x = x; where x itself is a zero only its sign can
+// differ, which no comparison of tri_test sees).
+__device__ __forceinline__ bool park_box_rejects(F3 v0, F3 e1, F3 e2, float ox, float4 b0, float4 b1)
+{
+    const Iv DY = {b1.x, b1.y}, DZ = {b1.z, b1.w};
+    const Iv hx = iv_sub(iv_mul_scalar(DY, e2.z), iv_mul_scalar(DZ, e2.y));
+    const Iv hy = iv_mul_scalar(DZ, e2.x);
+    const Iv t0 = iv_mul_scalar(DY, e2.x);
+    const Iv hz = {-t0.hi, -t0.lo};
+    const Iv a = iv_add(iv_add(iv_mul_scalar(hx, e1.x), iv_mul_scalar(hy, e1.y)), iv_mul_scalar(hz, e1.z));
+    if (a.lo > -0.00001f && a.hi < 0.00001f) return true;           // "a > -EPS && a < EPS" for every ray
+    if (!(a.lo > 1e-30f || a.hi < -1e-30f)) return false;           // some ray may see a (near) zero determinant
+    const Iv f = {1.0f / a.hi, 1.0f / a.lo};
+    const float sx = ox - v0.x;
+    const Iv sy = {b0.x - v0.y, b0.y - v0.y}, sz = {b0.z - v0.z, b0.w - v0.z};
+    const Iv du = iv_add(iv_add(iv_mul_scalar(hx, sx), iv_mul(sy, hy)), iv_mul(sz, hz));
+    const Iv u = iv_mul(f, du);
+    if (u.hi < 0.0f || u.lo > 1.0f) return true;
+    // q = cross(s, e1)
+    const Iv qx = iv_sub(iv_mul_scalar(sy, e1.z), iv_mul_scalar(sz, e1.y));
+    const float c1 = e1.z * sx, c2 = sx * e1.y;
+    const Iv m1 = iv_mul_scalar(sz, e1.x), m2 = iv_mul_scalar(sy, e1.x);
+    const Iv qy = {m1.lo - c1, m1.hi - c1};
+    const Iv qz = {c2 - m2.hi, c2 - m2.lo};
+    const Iv dv = iv_add(iv_mul(DY, qy), iv_mul(DZ, qz));
+    const Iv v = iv_mul(f, dv);
+    if (v.hi < 0.0f || u.lo + v.lo > 1.0f) return true;
+    const Iv dt = iv_add(iv_add(iv_mul_scalar(qx, e2.x), iv_mul_scalar(qy, e2.y)), iv_mul_scalar(qz, e2.z));
+    const Iv t = iv_mul(f, dt);
+    return !(t.hi > 0.00001f);
+}
+
+// One lane per leaf record of a leaf the family visits: boxes of 256, then 64, then 16 of the family's rays; the (record, 16 rays)
+// pairs that cannot be proven misses go to the family's queue.
+__global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int stats)
+{
     F3 O0, D0; uint32_t count;
     if (!reach_ray(p, O0, D0, count)) return;
-    const uint32_t* list = p.park_list + p.ray_slot * RT_PARK_SLOTS;
-    if (p.park_info[2 * RT_PARK_FAMILIES + p.ray_slot] & 1) {          // the visited set is not fixed: no result for these rays
+    const uint32_t fam = (uint32_t)p.ray_slot;
+    if (p.park_info[2 * RT_PARK_FAMILIES + fam] & 1) return;           // the visited set is not fixed: the test kernel flags the rays
+    const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+    bool use = false;
+    if (r < p.n_refs) use = p.reached[p.rec_leaf[r]] != 0;
+    if (stats) {
+        const uint32_t n = (uint32_t)__popcll(__ballot(use));
+        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * count);       // the tests the reference makes
+    }
+    if (!use) return;
+    const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1], r2 = p.leafrecs[3 * (size_t)r + 2];
+    const F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
+    const float big = 1e9f;
+    const bool tame = fabsf(v0.x) < big && fabsf(v0.y) < big && fabsf(v0.z) < big && fabsf(e1.x) < big && fabsf(e1.y) < big && fabsf(e1.z) < big &&
+                      fabsf(e2.x) < big && fabsf(e2.y) < big && fabsf(e2.z) < big && fabsf(O0.x) < big;
+    const float4* box16 = p.park_boxes + (size_t)fam * 2u * (RT_PARK_BOXES + 1u);
+    const float4* box64 = box16 + 2u * (RT_PARK_SLOTS / 16u);
+    const float4* box256 = box64 + 2u * (RT_PARK_SLOTS / 64u);
+    const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
+    uint2* queue = p.park_queue + (size_t)fam * p.park_queue_cap;
+    // Every ray of the family lies in the plane x = origin.x (direction.x is a zero), and a hit needs u, v >= 0, u + v <= 1 with,
+    // in exact arithmetic, u e1.x + v e2.x = origin.x - v0.x: the plane has to cross the triangle.  The computed u and v miss
+    // the exact ones by at most (7 u_r (S_u |e1.x| + S_v |e2.x|) + 5 u_r |s.x| A) / |a| in that combination (u_r = 2^-24; A, S_u, S_v
+    // the sums of the absolute values of the terms of the determinant and the two numerators), |a| >= 1e-5 or the test rejects
+    // anyway, and A <= 2 d |e1|_1 |e2|_1, S_u, S_v <= 2 d |s|_inf |e|_1 with d = max |direction component|: so a triangle whose
+    // x extent stays clear of the plane by more than 2 * 38 u_r d |s|_inf |e1|_1 |e2|_1 / 1e-5 (twice the first-order bound)
+    // fails the test for every ray of the family.  That is all but the few rows of triangles along the plane.
+    {
+        const float4 f0 = box16[2u * RT_PARK_BOXES], f1 = box16[2u * RT_PARK_BOXES + 1u];
+        if (tame && f0.x == f0.x) {
+            const float sx = O0.x - v0.x;
+            const float sy = fmaxf(fabsf(f0.x - v0.y), fabsf(f0.y - v0.y)), sz = fmaxf(fabsf(f0.z - v0.z), fabsf(f0.w - v0.z));
+            const float s_inf = fmaxf(fabsf(sx), fmaxf(sy, sz));
+            const float d = fmaxf(1.0f, fmaxf(fmaxf(fabsf(f1.x), fabsf(f1.y)), fmaxf(fabsf(f1.z), fabsf(f1.w))));
+            const float n1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z), n2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+            const float clear = (76.0f * 5.9604645e-8f * 1e5f) * d * s_inf * n1 * n2 + 4.0f * 5.9604645e-8f * ((fabsf(e1.x) + fabsf(e2.x)) + fabsf(sx));
+            const float xlo = fminf(0.0f, fminf(e1.x, e2.x)), xhi = fmaxf(0.0f, fmaxf(e1.x, e2.x));
+            if (sx < xlo - clear || sx > xhi + clear) return;
+        }
+    }
+    for (uint32_t c256 = 0; c256 < n256; ++c256) {
+        const float4 a0 = box256[2u * c256], a1 = box256[2u * c256 + 1u];
+        if (tame && a0.x == a0.x && park_box_rejects(v0, e1, e2, O0.x, a0, a1)) continue;
+        const uint32_t e64 = (c256 * 4u + 4u < n64) ? c256 * 4u + 4u : n64;
+        for (uint32_t c64 = c256 * 4u; c64 < e64; ++c64) {
+            const float4 b0 = box64[2u * c64], b1 = box64[2u * c64 + 1u];
+            if (tame && b0.x == b0.x && park_box_rejects(v0, e1, e2, O0.x, b0, b1)) continue;
+            const uint32_t e16 = (c64 * 4u + 4u < n16) ? c64 * 4u + 4u : n16;
+            for (uint32_t c16 = c64 * 4u; c16 < e16; ++c16) {
+                const float4 c0 = box16[2u * c16], c1 = box16[2u * c16 + 1u];
+                if (tame && c0.x == c0.x && park_box_rejects(v0, e1, e2, O0.x, c0, c1)) continue;
+                const uint32_t at = atomicAdd(p.park_queue_count + fam, 1u);
+                if (at < p.park_queue_cap) { queue[at] = make_uint2(r, c16); continue; }
+                // queue full: this lane makes the pair's sixteen tests itself (slow, but nothing is lost)
+                const uint32_t* list = p.park_list + fam * RT_PARK_SLOTS;
+                const uint32_t last = (c16 * 16u + 16u < count) ? c16 * 16u + 16u : count;
+                for (uint32_t k = c16 * 16u; k < last; ++k) {
+                    const uint32_t sl = list[k];
+                    const float4 o4 = p.resume_paths[RT_PARK_WORDS * sl], d4 = p.resume_paths[RT_PARK_WORDS * sl + 1];
+                    float tt, u, v;
+                    if (tri_test(r0, r1, r2, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z), tt, u, v))
+                        atomicMin(&p.park_best[sl], ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r);
+                }
+            }
+        }
+    }
+}
+
+// The real triangle test for the queued (record, 16 rays) pairs of a family: 16 lanes per pair, min (t, record index) per ray.
+// A family whose visited set depends on t gets no result: its rays are flagged and their waves walk.
+__global__ __launch_bounds__(256) void rt_park_test_kernel(RtParams p)
+{
+    F3 O0, D0; uint32_t count;
+    if (!reach_ray(p, O0, D0, count)) return;
+    const uint32_t fam = (uint32_t)p.ray_slot;
+    const uint32_t* list = p.park_list + fam * RT_PARK_SLOTS;
+    if (p.park_info[2 * RT_PARK_FAMILIES + fam] & 1) {
         if (blockIdx.x == 0) for (uint32_t k = threadIdx.x; k < count; k += 256u) p.park_flags[list[k]] = 1u;
         return;
     }
-    for (uint32_t first = 0; first < count; first += RT_PARK_CHUNK) {
-        const uint32_t chunk = count - first < RT_PARK_CHUNK ? count - first : RT_PARK_CHUNK;
-        __syncthreads();
-        for (uint32_t k = threadIdx.x; k < chunk; k += 256u) {
-            const uint32_t sl = list[first + k];
-            const float4 o4 = p.resume_paths[RT_PARK_WORDS * sl], d4 = p.resume_paths[RT_PARK_WORDS * sl + 1];
-            ray_o[k] = make_float4(o4.x, o4.y, o4.z, __uint_as_float(sl)); ray_d[k] = d4;
-        }
-        __syncthreads();
-        for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r - threadIdx.x < p.n_refs; r += gridDim.x * 256u) {
-            bool use = false;
-            float4 r2 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (r < p.n_refs) use = p.reached[p.rec_leaf[r]] != 0;
-            if (stats) {
-                const uint32_t n = (uint32_t)__popcll(__ballot(use));
-                if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * chunk);
-            }
-            if (!use) continue;
-            const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1];
-            r2 = p.leafrecs[3 * (size_t)r + 2];
-            const F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
-            for (uint32_t k = 0; k < chunk; ++k) {
-                const float4 o4 = ray_o[k], d4 = ray_d[k];
-                const F3 O = f3(o4.x, o4.y, o4.z), D = f3(d4.x, d4.y, d4.z);
-                // The first values of tri_test, and what they already decide without its division: u = (1 / a) * su has the sign
-                // of su * a when neither factor is tiny, and |u| >= 2 (1 - 2^-23) when |su| > 2 |a|: either way u is outside [0, 1].
-                const F3 h = cross3(D, e2);
-                const float a = dot3(e1, h);
-                const float su = dot3(O - v0, h);
-                const float aa = fabsf(a), asu = fabsf(su);
-                const bool reject = (a > -0.00001f && a < 0.00001f) || ((su < 0.0f) != (a < 0.0f) && asu > 1e-18f && aa < 1e18f) || asu > 2.0f * aa;
-                if (reject) continue;
-                float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)r;
-                    atomicMin(&p.park_best[__float_as_uint(o4.w)], key);
-                }
-            }
+    const uint32_t n = p.park_queue_count[fam] < p.park_queue_cap ? p.park_queue_count[fam] : p.park_queue_cap;
+    const uint2* queue = p.park_queue + (size_t)fam * p.park_queue_cap;
+    const uint32_t sub = threadIdx.x & 15u;
+    for (uint32_t e = blockIdx.x * 16u + (threadIdx.x >> 4); e < n; e += gridDim.x * 16u) {
+        const uint2 pr = queue[e];
+        const uint32_t k = pr.y * 16u + sub;
+        if (k >= count) continue;
+        const uint32_t sl = list[k];
+        const float4* rec = p.leafrecs + 3 * (size_t)pr.x;
+        const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const float4 o4 = p.resume_paths[RT_PARK_WORDS * sl], d4 = p.resume_paths[RT_PARK_WORDS * sl + 1];
+        float tt, u, v;
+        if (tri_test(r0, r1, r2, f3(o4.x, o4.y, o4.z), f3(d4.x, d4.y, d4.z), tt, u, v)) {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(tt) << 32) | (unsigned long long)pr.x;
+            atomicMin(&p.park_best[sl], key);
         }
     }
 }
@@ -1670,11 +1826,16 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
                     wprune = FLT_MAX; wflag = false;
                     if (ORDERED && RT_NEAR_TIES) {
-                        // A box's entry distance is rounded differently from the hit distance of a triangle inside it: by up
-                        // to a few units in the last place of |plane - origin| / |direction component|.
-                        const float reach = ((fabsf(s.O.x - p.root_center[0]) + fabsf(s.O.y - p.root_center[1])) + fabsf(s.O.z - p.root_center[2])) + p.root_reach;
-                        const float steep = fmaxf(fabsf(winvD.x), fmaxf(fabsf(winvD.y), fabsf(winvD.z)));
-                        wtol = reach * steep * (RT_TIE_ULPS * 1.1920929e-7f);
+                        // The part of the near-tie distance that does not grow with t (see RtParams::tie_*): the rounding of a box's
+                        // entry distance, per axis a few units in the last place of (|plane - origin| + |plane|) * |1 / direction|,
+                        // and the constant part of the triangle test's error bound.  The bounds assume |direction| <= 1 per
+                        // component; a longer (host-supplied) direction gets an infinite distance: never pruned by a margin,
+                        // any two different hits repeated in the reference's order.
+                        const float bx = (fabsf(s.O.x - p.root_center[0]) + p.tie_box[0]) * fabsf(winvD.x);
+                        const float by = (fabsf(s.O.y - p.root_center[1]) + p.tie_box[1]) * fabsf(winvD.y);
+                        const float bz = (fabsf(s.O.z - p.root_center[2]) + p.tie_box[2]) * fabsf(winvD.z);
+                        wtol = fmaxf(bx, fmaxf(by, bz)) * p.tie_ulp + p.tie_abs;
+                        if (fmaxf(fabsf(s.D.x), fmaxf(fabsf(s.D.y), fabsf(s.D.z))) > 1.001f) wtol = __builtin_inff();
                     }
                     phase = PH_WALK;
                 }
@@ -1728,7 +1889,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, h, best);
                         if ((int)lane == src) {
                             th = h; wbest = best; wnode = end;
-                            wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + RT_TIE_REL * h.t) : h.t;
+                            wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + p.tie_rel * h.t) : h.t;
                             if (near_tie || wflag) { phase = PH_REDO; wflag = false; atomicAdd(p.column_stats + 2, 1ull); }
                             else phase = PH_SHADE;
                         }
@@ -1768,10 +1929,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         float tt, u, v;
                         if (tri_test(r0, r1, r2, s.O, s.D, tt, u, v)) {
                             const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
-                            if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + RT_TIE_REL * fminf(tt, th.t)) wflag = true;
+                            if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + p.tie_rel * fminf(tt, th.t)) wflag = true;
                             if (tt < th.t || (ORDERED && tt == th.t && wrec < wbest)) {
                                 th.t = tt; th.id = id; th.u = u; th.v = v; wbest = wrec;
-                                wprune = RT_NEAR_TIES ? tt + (wtol + RT_TIE_REL * tt) : tt;
+                                wprune = RT_NEAR_TIES ? tt + (wtol + p.tie_rel * tt) : tt;
                             }
                         }
                         const bool more = (tag & 0x80000000u) == 0u;
@@ -2002,18 +2163,19 @@ extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int
     return hipGetLastError();
 }
 
-// The hits of the parked paths of the resume list, family by family: visited nodes, then every record of a visited leaf
-// against every ray of the family.  The resume launch of the trace kernel follows.
+// The hits of the parked paths of the resume list, family by family: the families sorted and boxed, per family the visited
+// nodes, the interval filter over the records of the visited leaves, the real test on what is left.  The resume launch of
+// the trace kernel follows.
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s)
 {
     RtParams q = *p;
     hipLaunchKernelGGL(rt_park_group_kernel, dim3(1), dim3(1024), 0, s, q);
+    hipLaunchKernelGGL(rt_park_sort_kernel, dim3(RT_PARK_FAMILIES), dim3(1024), 0, s, q);
     for (int family = 0; family < RT_PARK_FAMILIES; ++family) {
         q.ray_slot = family;
         launch_reach(q, stats, s);
-        if (q.n_refs == 0u) continue;                                          // no triangle to test: park_best stays "miss"
-        const unsigned rec_blocks = (q.n_refs + 255u) / 256u;
-        hipLaunchKernelGGL(rt_park_test_kernel, dim3(rec_blocks < 4096u ? rec_blocks : 4096u), dim3(256), 0, s, q, stats);
+        if (q.n_refs != 0u) hipLaunchKernelGGL(rt_park_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
+        hipLaunchKernelGGL(rt_park_test_kernel, dim3(2048), dim3(256), 0, s, q);       // (a tree without a triangle: every ray misses)
     }
     return hipGetLastError();
 }

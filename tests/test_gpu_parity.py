@@ -270,13 +270,35 @@ def test_front_to_back_near_ties_fall_back_to_the_reference_walk(rt, orc, render
 
 
 def test_auto_order_follows_the_tree(rt, orc, renderer):
-    """A tree of the reference builder is a KD tree: RT_ORDER_AUTO walks it front to back.  The same tree with two sibling
-    boxes swapped in position is not (its children no longer tile their parent): AUTO falls back to the reference order."""
+    """A tree of the reference builder over a finely tessellated mesh is a KD tree with complete leaf lists and a small near-tie
+    distance: RT_ORDER_AUTO walks it front to back.  The same tree with a child box that no longer reaches the split plane is not a
+    KD tree, a tree with a triangle missing from one of its leaves has incomplete lists, and a coarse mesh (large triangles: the
+    error bound of the triangle test grows with their size) would repeat too many rays: AUTO takes the reference order for those."""
     from raytracer_amd import scenes, _capi
-    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(24))
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(140))
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(64, 48)
     st = renderer.GetSettings(); st.SceneMode, st.TraversalOrder = 0, _capi.ORDER_AUTO
     renderer.OnResize(64, 48); renderer.upload(scene, cam)
+    assert renderer.traversal_in_use() == _capi.ORDER_FRONT_TO_BACK
+    coarse, _ = make_scene(rt, orc, mesh=scenes.displaced_grid(24))
+    renderer.upload(coarse, cam)
+    assert renderer.traversal_in_use() == _capi.ORDER_REFERENCE
+    a = scene.kd_tree.arrays()
+    cnt = None
+    for leaf in np.flatnonzero((a["left"] < 0) & (a["right"] < 0) & (a["count"] > 1)):
+        tri = a["leaf_idx"][a["first"][leaf] + a["count"][leaf] - 1]
+        v = scene.verts[scene.tri_idx[tri]]
+        lo, hi = a["center"][leaf] - 0.99 * a["extent"][leaf], a["center"][leaf] + 0.99 * a["extent"][leaf]
+        if np.all(v.min(0) < hi) and np.all(v.max(0) > lo):             # well inside the leaf's box, not just touching it
+            cnt = a["count"].copy(); cnt[leaf] -= 1                      # the leaf forgets its last triangle
+            break
+    assert cnt is not None
+    scene3 = rt.Scene(); scene3.materials = scene.materials; scene3.spheres = scene.spheres
+    scene3.set_triangles(scene.verts, scene.tri_idx, scene.normals9, scene.tri_mat, build_kd=False)
+    scene3.kd_tree = rt.FlatKDTree(a["center"], a["extent"], a["left"], a["right"], a["first"], cnt, a["leaf_idx"])
+    renderer.upload(scene3, cam)
+    assert renderer.traversal_in_use() == _capi.ORDER_REFERENCE
+    renderer.upload(scene, cam)
     assert renderer.traversal_in_use() == _capi.ORDER_FRONT_TO_BACK
     a = scene.kd_tree.arrays()
     ext = a["extent"].copy()

@@ -3,10 +3,11 @@
 # per PMC counter group (counters never share a run with a trace domain; every pass has its own time limit).
 set -u
 CFG=${1:-2}
-OUT=gpurun_out/prof_cfg${CFG}
+KIND=${2:-single}            # single: one Render per launch; throughput: launches of 16 Renders
+OUT=gpurun_out/prof_cfg${CFG}_${KIND}
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --config ${CFG} --steps 16 --warmup 3 --no-cpu-baseline"
+BENCH="python3 bench.py --config ${CFG} --steps 16 --warmup 3 --no-cpu-baseline --profile ${KIND}"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace pass failed"; tail -5 $OUT/trace.log; exit 1; }
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" \
