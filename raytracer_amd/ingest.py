@@ -11,8 +11,10 @@
     Roughness = (1024 - Ns) / 1024, IOR = Ni, Transparency = 1 for the material named "water", 0 otherwise; tinyobjloader's
     defaults for missing statements are Kd = Ks = Ke = 0, Ns = 1, Ni = 1 (tiny_obj_loader.h:1358-1392);
   * quads are cut along the shorter diagonal, compared in single precision: [0,1,2],[0,2,3] when |v2-v0|^2 < |v3-v1|^2, else
-    [0,1,3],[1,2,3] (tiny_obj_loader.h:1488-1583).  Polygons with more than four corners are fanned from corner 0 here; the
-    reference's loader ear-clips them, so their triangle order is not pinned.
+    [0,1,3],[1,2,3] (tiny_obj_loader.h:1488-1583); polygons with more than four corners are ear-clipped as the loader's built-in
+    triangulation does (tiny_obj_loader.h:1714-1935, the application does not enable the earcut alternative): same projection
+    axes, same ear test, same order of the emitted triangles.  tests/golden/ref_obj_polygons.npz holds what the reference's own
+    loader returns for tests/golden/polygons.obj.
 
 The application appends its own seven materials after the file's (RaytracerApp.cpp:132-187): `load_obj(..., app_materials=True)`.
 
@@ -64,6 +66,69 @@ def _index(tok, n):
     return i - 1 if i > 0 else n + i            # OBJ indices are 1-based; negative = relative to the end
 
 
+def _pnpoly(vx, vy, tx, ty):
+    """Point-in-triangle parity test of the loader (tiny_obj_loader.h:1411-1422), single precision."""
+    c = False
+    j = 2
+    for i in range(3):
+        if (vy[i] > ty) != (vy[j] > ty) and tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]:
+            c = not c
+        j = i
+    return c
+
+
+def _ear_clip(face_pos):
+    """The loader's built-in triangulation of a polygon with more than four corners (tiny_obj_loader.h:1714-1935), in single
+    precision: corner triples (indices into the face) in the order the loader emits them."""
+    n = len(face_pos)
+    P = [np.array(q, f32) for q in face_pos]
+    axes = [1, 2]
+    eps = np.finfo(f32).eps
+    for k in range(n):                                                      # the first real corner decides the projection plane
+        v0, v1, v2 = P[k % n], P[(k + 1) % n], P[(k + 2) % n]
+        e0, e1 = v1 - v0, v2 - v1
+        cx = abs(e0[1] * e1[2] - e0[2] * e1[1]); cy = abs(e0[2] * e1[0] - e0[0] * e1[2]); cz = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        if cx > eps or cy > eps or cz > eps:
+            if not (cx > cy and cx > cz):
+                axes[0] = 0
+                if cz > cx and cz > cy:
+                    axes[1] = 1
+            break
+    remaining = list(range(n))
+    out = []
+    guess, iterations, previous = 0, n, n
+    while len(remaining) > 3 and iterations > 0:
+        m = len(remaining)
+        if guess >= m:
+            guess -= m
+        if previous != m:
+            previous, iterations = m, m
+        else:
+            iterations -= 1
+        ind = [remaining[(guess + k) % m] for k in range(3)]
+        vx = [P[i][axes[0]] for i in ind]; vy = [P[i][axes[1]] for i in ind]
+        e0x, e0y, e1x, e1y = vx[1] - vx[0], vy[1] - vy[0], vx[2] - vx[1], vy[2] - vy[1]
+        cross = e0x * e1y - e0y * e1x
+        area = (vx[0] * vy[1] - vy[0] * vx[1]) * f32(0.5)
+        if cross * area < f32(0.0):                                         # "an internal angle"
+            guess += 1
+            continue
+        overlap = False
+        for other in range(3, m):
+            q = P[remaining[(guess + other) % m]]
+            if _pnpoly(vx, vy, q[axes[0]], q[axes[1]]):
+                overlap = True
+                break
+        if overlap:
+            guess += 1
+            continue
+        out.append(tuple(ind))                                              # an ear: its middle corner leaves the polygon
+        del remaining[(guess + 1) % m]
+    if len(remaining) == 3:
+        out.append(tuple(remaining))
+    return out
+
+
 def load_obj(path, app_materials=False):
     """Returns (verts (3T,3) f32, tri_idx (T,3) u32, normals9 (T,9) f32, tri_mat (T,) u32, materials, names)."""
     positions, normals, mtl, names = [], [], [], {}
@@ -107,7 +172,8 @@ def load_obj(path, app_materials=False):
                     sqr13 = (e13[0] * e13[0] + e13[1] * e13[1]) + e13[2] * e13[2]
                     tris = [(0, 1, 2), (0, 2, 3)] if sqr02 < sqr13 else [(0, 1, 3), (1, 2, 3)]
                 else:
-                    tris = [(0, k, k + 1) for k in range(1, len(face) - 1)]
+                    with np.errstate(all="ignore"):
+                        tris = _ear_clip([positions[v] for v, _ in face])
                 for t in tris:
                     corners.append([face[k] for k in t])
                     face_mat.append(max(cur_mat, 0))

@@ -103,3 +103,31 @@ def test_ingested_scene_renders_like_the_oracle(box, orc):
         assert np.array_equal(bits(r.read_accum().reshape(-1, 3)), bits(acc))
         assert np.array_equal(bits(r.GetImage().data.reshape(-1, 4)), bits(img))
         assert (ids >= 0x40000000).sum() > 2000
+
+
+def test_polygons_are_triangulated_like_the_reference_loader():
+    """Polygons with five to eight corners, convex and concave, in four different planes: the triangles, their order and their
+    corner order equal what the reference's own tiny_obj_loader.h returns (tests/golden/ref_obj_polygons.npz, generated from the
+    unmodified header by tests/golden/make_golden_obj.py)."""
+    import os
+    from conftest import ROOT
+    from raytracer_amd import ingest
+    gold = os.path.join(ROOT, "tests", "golden")
+    g = np.load(os.path.join(gold, "ref_obj_polygons.npz"))
+    verts, tri_idx, normals9, tri_mat, mats, names = ingest.load_obj(os.path.join(gold, "polygons.obj"))
+    pos, nrm = [], []
+    with open(os.path.join(gold, "polygons.obj")) as fh:
+        for line in fh:
+            tok = line.split("#", 1)[0].split()
+            if tok and tok[0] == "v":
+                pos.append([float(x) for x in tok[1:4]])
+            elif tok and tok[0] == "vn":
+                nrm.append([float(x) for x in tok[1:4]])
+    pos, nrm = np.array(pos, np.float32), np.array(nrm, np.float32)
+    assert len(tri_idx) == len(g["v_idx"]) == 26
+    assert np.array_equal(verts, pos[g["v_idx"].reshape(-1)])              # same triangles, same order, same corner order
+    want_n = np.where(g["n_idx"].reshape(-1, 1) >= 0, nrm[np.maximum(g["n_idx"].reshape(-1), 0)], np.array([0.0, 1.0, 0.0], np.float32))
+    assert np.array_equal(normals9.reshape(-1, 3), want_n)                 # unit normals in the file: normalising leaves them
+    assert not np.array_equal(g["v_idx"][17:19], [[19, 24, 25], [19, 25, 26]])   # (a fan from corner 0 would differ on the star)
+    assert np.all(tri_mat == 0)
+

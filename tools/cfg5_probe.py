@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Config 5 (spheres + 10 M triangles at 4K): ms per frame with one Render per launch and with 16 per launch, printed as it goes
-(run on the GPU box from the repo root)."""
+"""A tree configuration of bench.py (default 5: spheres + 10 M triangles at 4K): ms per frame with one Render per launch and with
+16 per launch, printed as it goes (run on the GPU box from the repo root; PROBE_BOUNCES=<n> overrides the bounce count)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -10,7 +10,7 @@ cfg = bench.CONFIGS[int(sys.argv[1]) if len(sys.argv) > 1 else 5]
 t0 = time.perf_counter(); scene = bench.build_scene(cfg); print("scene %.1f s" % (time.perf_counter() - t0), flush=True)
 cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(cfg["w"], cfg["h"])
 r = rt.Renderer(0); r.download = False
-st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
+st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], int(os.environ.get("PROBE_BOUNCES", cfg["bounces"]))
 r.OnResize(cfg["w"], cfg["h"])
 t0 = time.perf_counter(); r.upload(scene, cam); r.sync(); print("upload %.1f s" % (time.perf_counter() - t0), flush=True)
 for per in (1, 1, 16, 16):
