@@ -406,6 +406,30 @@ def test_sixteen_frames_per_launch_and_deep_accumulation(rt, orc, renderer, mode
     assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(img))
 
 
+@pytest.mark.parametrize("mode", [1, 2], ids=["spheres", "spheres+mesh"])
+def test_thousand_frame_accumulation(rt, orc, renderer, mode):
+    """1024 accumulated frames (the depth of the progressive configuration) at a small size, as launches of up to 16 Renders,
+    against the oracle's frame-by-frame sum: every bit of the sum and of the last frame's image."""
+    from raytracer_amd import scenes
+    w, h, n = 48, 32, 1024
+    mesh = None if mode == 1 else scenes.displaced_grid(16, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0)
+    scene, osc = make_scene(rt, orc, mesh=mesh)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = mode, 5, True, False, True, 1337, 0
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.set_stats(False)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    ost = orc.Settings(1, mode, 1, 0, 5)
+    for f in range(1, n + 1):
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img)
+    renderer.Render(scene, cam, frames=1000)
+    renderer.Render(scene, cam, frames=24)
+    assert renderer.GetFrameIndex() == n + 1
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(acc))
+    assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(img))
+
+
 def test_accumulate_off_and_reset(rt, orc, renderer):
     scene, osc = make_scene(rt, orc)
     w, h = 100, 60
