@@ -6,6 +6,10 @@
 //     std::shared_ptr<Image> GetImage();  void ResetFrameIndex();  uint32_t GetFrameIndex();
 // so RaytracerLayer (RayTracer/src/RaytracerApp.cpp:259-366) compiles against it unchanged:
 //     using Renderer = RendererHIP<Scene, Camera, Walnut::Image, Walnut::ImageFormat::RGBA32F>;
+// Default-constructed it renders on GPU 0.  RendererHIP(devices, RT_SPLIT_TILES | RT_SPLIT_SAMPLES) spreads every Render over
+// several GPUs of the node from this one process (rt_group_*): by 16-row bands of the frame (single frames: the result is the
+// one-GPU frame bit for bit), or by frame index (progressive accumulation: one Render then adds one frame per GPU and
+// GetFrameIndex advances by their number).
 //
 // The template parameters are the reference's own types (Scene.h:37-44, Camera.h:6-48, Walnut/Image.h:16-52); they are
 // parameters only so that this header can also be instantiated with light stand-ins where Vulkan is absent.
@@ -81,11 +85,16 @@ public:
     };
     Settings& GetSettings() { return m_settings; }
 
-    explicit RendererHIP(int device = 0) : m_ctx(rt_create(device))
+    enum Split { RT_SPLIT_TILES = 0, RT_SPLIT_SAMPLES = 1 };
+
+    explicit RendererHIP(int device = 0) : RendererHIP(std::vector<int>{device}, RT_SPLIT_TILES) {}
+    RendererHIP(const std::vector<int>& devices, Split split)
+        : m_group(rt_group_create(devices.data(), (int)devices.size())), m_split(split)
     {
-        if (!m_ctx) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        if (!m_group) throw std::runtime_error(std::string("rt_group_create: ") + rt_last_error(nullptr));
+        m_ctx = rt_group_ctx(m_group, 0);
     }
-    ~RendererHIP() { rt_destroy(m_ctx); }
+    ~RendererHIP() { rt_group_destroy(m_group); }
     RendererHIP(const RendererHIP&) = delete;
     RendererHIP& operator=(const RendererHIP&) = delete;
 
@@ -93,7 +102,8 @@ public:
     void OnResize(uint32_t width, uint32_t height)
     {
         if (m_Image && m_Image->GetWidth() == width && m_Image->GetHeight() == height) return;
-        check(rt_resize(m_ctx, width, height), "rt_resize");      // first: if it throws, image and context still agree
+        for (int i = 0; i < rt_group_size(m_group); ++i)          // first: if it throws, image and contexts still agree
+            check(rt_group_ctx(m_group, i), rt_resize(rt_group_ctx(m_group, i), width, height), "rt_resize");
         if (m_Image) m_Image->Resize(width, height);
         else m_Image = std::make_shared<ImageT>(width, height, kFormat);
         ResetFrameIndex();
@@ -106,7 +116,6 @@ public:
         st.accumulate = m_settings.Accumulate; st.scene_mode = m_settings.UseSphereScene ? RT_SCENE_SPHERES : RT_SCENE_MESH;
         st.use_ace = m_settings.UseACE_Color; st.anti_aliasing = m_settings.AntiAliasing;
         st.bounces = m_settings.Bounces; st.seed = 1337; st.traversal = m_settings.TraversalOrder;
-        check(rt_set_settings(m_ctx, &st), "rt_set_settings");
 
         // spheres and materials are edited live by the UI (RaytracerApp.cpp:283-331): sent every frame (a few hundred bytes)
         m_spheres.resize(scene.spheres.size());
@@ -120,18 +129,24 @@ public:
             m_materials[i] = rt_material{{m.Albedo[0], m.Albedo[1], m.Albedo[2]}, {m.Emission[0], m.Emission[1], m.Emission[2]},
                                          m.Roughness, m.Transparency, m.IOR};
         }
-        check(rt_set_materials(m_ctx, m_materials.data(), (uint32_t)m_materials.size()), "rt_set_materials");
-        check(rt_set_spheres(m_ctx, m_spheres.data(), (uint32_t)m_spheres.size()), "rt_set_spheres");
-
         // mesh + KD tree are immutable after the layer's constructor (RaytracerApp.cpp:130): uploaded once per tree object
         if (scene.kd_tree && (const void*)&*scene.kd_tree != m_tree_key) upload_mesh(scene);
 
         const auto& pos = camera.GetPosition();
         const float p3[3] = {pos[0], pos[1], pos[2]};
-        check(rt_set_camera(m_ctx, p3, &camera.GetInverseProjection()[0][0], &camera.GetInverseView()[0][0]), "rt_set_camera");
-
-        check(rt_render(m_ctx, m_frameindex), "rt_render");
-        if (m_settings.Accumulate) m_frameindex++; else m_frameindex = 1;      // Renderer.cpp:128-131
+        const int n = rt_group_size(m_group);
+        for (int i = 0; i < n; ++i) {                       // every GPU of the group holds the same scene and camera
+            rt_ctx* c = rt_group_ctx(m_group, i);
+            check(c, rt_set_settings(c, &st), "rt_set_settings");
+            check(c, rt_set_materials(c, m_materials.data(), (uint32_t)m_materials.size()), "rt_set_materials");
+            check(c, rt_set_spheres(c, m_spheres.data(), (uint32_t)m_spheres.size()), "rt_set_spheres");
+            check(c, rt_set_camera(c, p3, &camera.GetInverseProjection()[0][0], &camera.GetInverseView()[0][0]), "rt_set_camera");
+        }
+        uint32_t frames = 1;
+        if (n == 1) check(rt_render(m_ctx, m_frameindex), "rt_render");
+        else if (m_split == RT_SPLIT_TILES) gcheck(rt_group_render_tiles(m_group, m_frameindex, 1), "rt_group_render_tiles");
+        else { gcheck(rt_group_render_samples(m_group, m_frameindex, 1), "rt_group_render_samples"); frames = (uint32_t)n; }
+        if (m_settings.Accumulate) m_frameindex += frames; else m_frameindex = 1;      // Renderer.cpp:128-131
         // page-locked staging owned by the library
         const float* frame = m_settings.PipelinedHandoff ? rt_map_image_pipelined(m_ctx) : rt_map_image(m_ctx);
         if (!frame) check(RT_E_HIP, "rt_map_image");
@@ -142,12 +157,18 @@ public:
     void ResetFrameIndex() { m_frameindex = 1; }
     uint32_t GetFrameIndex() { return m_frameindex; }
 
-    rt_ctx* context() { return m_ctx; }
+    rt_ctx* context() { return m_ctx; }          // the context that assembles and hands off the frame (GPU devices[0])
+    rt_group* group() { return m_group; }
 
 private:
-    void check(int rc, const char* what)
+    void check(int rc, const char* what) { check(m_ctx, rc, what); }
+    void check(rt_ctx* c, int rc, const char* what)
     {
-        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_last_error(m_ctx));
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_last_error(c));
+    }
+    void gcheck(int rc, const char* what)
+    {
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_group_last_error(m_group));
     }
 
     void upload_mesh(const SceneT& scene)
@@ -163,15 +184,20 @@ private:
             for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) normals[9 * (size_t)t + 3 * c + k] = tri.Normals[c][k];
             mats[t] = (uint32_t)tri.MaterialIndex;
         }
-        check(rt_set_mesh(m_ctx, verts.data(), nverts, idx.data(), normals.data(), mats.data(), ntris), "rt_set_mesh");
         RtFlatTree flat;
         rt_flatten_kdtree(kd.getRootNode(), flat);
         const rt_kd_flat view = flat.view();
-        check(rt_set_kdtree(m_ctx, &view), "rt_set_kdtree");
+        for (int i = 0; i < rt_group_size(m_group); ++i) {
+            rt_ctx* c = rt_group_ctx(m_group, i);
+            check(c, rt_set_mesh(c, verts.data(), nverts, idx.data(), normals.data(), mats.data(), ntris), "rt_set_mesh");
+            check(c, rt_set_kdtree(c, &view), "rt_set_kdtree");
+        }
         m_tree_key = (const void*)&kd;
     }
 
-    rt_ctx* m_ctx;
+    rt_group* m_group;
+    rt_ctx* m_ctx = nullptr;
+    Split m_split;
     Settings m_settings;
     std::shared_ptr<ImageT> m_Image;
     std::vector<rt_sphere> m_spheres;

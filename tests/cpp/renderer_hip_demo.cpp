@@ -10,6 +10,8 @@
 // out.bin  : u32 frame_index_after, n_kd_nodes; image w*h*4 f32 (what Image::SetData received); accumulation w*h*3 f32
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "Scene.h"
 #include "Camera.h"
@@ -33,7 +35,8 @@ template <class T> static bool rd(FILE* f, T* p, size_t n) { return fread(p, siz
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) { fprintf(stderr, "usage: %s scene.bin out.bin\n", argv[0]); return 2; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s scene.bin out.bin [contexts on GPU 0, tile split]\n", argv[0]); return 2; }
+    const int n_ctx = argc == 4 ? atoi(argv[3]) : 1;
     FILE* f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 2; }
     uint32_t hd[9];
@@ -71,7 +74,7 @@ int main(int argc, char** argv)
     if (nt) scene.kd_tree = std::make_shared<KDTreeCPU>((int)nt, tris.data(), (int)nv, verts.data());   // the reference builder
 
     Camera camera(70.0f, 0.05f, 100.0f);                   // RaytracerApp.cpp:24
-    Renderer renderer(0);
+    Renderer renderer(std::vector<int>((size_t)(n_ctx < 1 ? 1 : n_ctx), 0), Renderer::RT_SPLIT_TILES);   // one context: as Renderer renderer(0)
     renderer.GetSettings().UseSphereScene = use_spheres != 0;
     renderer.GetSettings().Bounces = bounces;
     for (uint32_t i = 0; i < frames; ++i) {                 // RaytracerLayer::Render, RaytracerApp.cpp:355-366
@@ -79,8 +82,15 @@ int main(int argc, char** argv)
         camera.OnResize(w, h);
         renderer.Render(scene, camera);
     }
-    std::vector<float> accum((size_t)3 * w * h);
-    if (rt_read_accum(renderer.context(), accum.data()) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error(renderer.context())); return 1; }
+    // the accumulation buffer: every context holds the sums of its own 16-row bands (one context: all of them)
+    std::vector<float> accum((size_t)3 * w * h), part((size_t)3 * w * h);
+    const int n_in_group = rt_group_size(renderer.group());
+    for (int i = 0; i < n_in_group; ++i) {
+        rt_ctx* c = rt_group_ctx(renderer.group(), i);
+        if (rt_read_accum(c, part.data()) != RT_OK) { fprintf(stderr, "%s\n", rt_last_error(c)); return 1; }
+        for (uint32_t y = 0; y < h; ++y)
+            if ((int)((y / 16u) % (uint32_t)n_in_group) == i) memcpy(&accum[(size_t)3 * w * y], &part[(size_t)3 * w * y], (size_t)3 * w * sizeof(float));
+    }
     uint32_t n_nodes = 0;
     if (nt) { RtFlatTree flat; rt_flatten_kdtree(scene.kd_tree->getRootNode(), flat); n_nodes = (uint32_t)flat.left.size(); }
 

@@ -734,8 +734,8 @@ def test_bench_distributed_code_path_with_one_rank():
 
 
 # ---- the drop-in itself: RendererHIP with the reference's own Scene / Camera / KDTreeCPU ------------------------------------------
-@pytest.mark.parametrize("use_spheres", [1, 0])
-def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
+@pytest.mark.parametrize("use_spheres,contexts", [(1, 1), (0, 1), (0, 3)], ids=["spheres", "mesh", "mesh-3-contexts"])
+def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres, contexts):
     """oracle/_ref/renderer_hip_demo links the reference's unmodified Scene.h, Camera.cpp and KDTreeCPU (its real builder)
     with include/RendererHIP.h in place of Renderer; what it hands to Image::SetData and its accumulation buffer must equal
     the oracle's.  (The binary is built where the reference tree exists and travels with the repo.)"""
@@ -753,7 +753,9 @@ def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres):
         f.write(spheres.tobytes()); f.write(mats.tobytes())
         f.write(verts.astype(np.float32).tobytes()); f.write(tris.astype(np.uint32).tobytes())
         f.write(normals9.astype(np.float32).tobytes()); f.write(tri_mat.astype(np.uint32).tobytes())
-    p = subprocess.run([demo, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+    # (contexts > 1: RendererHIP over a group of contexts on GPU 0, tile split -- the frame must not change)
+    p = subprocess.run([demo, str(tmp_path / "scene.bin"), str(tmp_path / "out.bin")] + ([str(contexts)] if contexts > 1 else []),
+                       capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:] + p.stdout[-500:]
     raw = np.fromfile(tmp_path / "out.bin", np.uint8)
     tail = raw[:8].view(np.uint32)

@@ -1,32 +1,37 @@
 #!/usr/bin/env python3
 """Copy the rocprofv3 summaries of tools/profile.sh from gpurun_out/ into profiles/ (tracked) under a round tag, and derive
 profiles/traffic.json (HBM bytes per trace-kernel launch: 2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE doubled because gfx950
-reports half of the bytes of wide coalesced reads; both counters are in KiB)."""
+reports half of the bytes of wide coalesced reads; both counters are in KiB) from the one-Render-per-launch passes.
+
+    python tools/collect_profiles.py r2        # after tools/profile.sh N single|throughput runs on the GPU box"""
 import glob, json, os, shutil, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 traffic_path = os.path.join(root, "profiles", "traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 for cfg in (1, 2, 3, 4, 5):
-    d = os.path.join(root, "gpurun_out", "prof_cfg%d" % cfg)
-    summ = os.path.join(root, "gpurun_out", "prof_cfg%d_summary.json" % cfg)
-    if not os.path.exists(summ):
-        continue
-    stats = sorted(glob.glob(d + "/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
-    if stats:                                            # the newest: gpurun merges every run's files into the same directory
-        shutil.copy(stats[-1], os.path.join(root, "profiles", "%s_cfg%d_kernel_stats.csv" % (tag, cfg)))
-    shutil.copy(summ, os.path.join(root, "profiles", "%s_cfg%d_pmc_summary.json" % (tag, cfg)))
-    b = os.path.join(root, "gpurun_out", "bench_cfg%d.json" % cfg)
-    if os.path.exists(b):
-        shutil.copy(b, os.path.join(root, "profiles", "%s_cfg%d_bench.json" % (tag, cfg)))
-    s = json.load(open(summ))
-    for k, cs in s["counters"].items():
-        # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
-        timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
-        if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            traffic["config%d" % cfg] = {
-                "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
-                "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0,
-                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh %d, round tag %s" % (cfg, tag)}
+    for kind in ("single", "throughput"):
+        d = os.path.join(root, "gpurun_out", "prof_cfg%d_%s" % (cfg, kind))
+        summ = d + "_summary.json"
+        if not os.path.exists(summ):
+            continue
+        name = "%s_cfg%d_%s" % (tag, cfg, kind)
+        stats = sorted(glob.glob(d + "/trace/**/*_kernel_stats.csv", recursive=True), key=os.path.getmtime)
+        if stats:                                        # the newest: gpurun merges every run's files into the same directory
+            shutil.copy(stats[-1], os.path.join(root, "profiles", name + "_kernel_stats.csv"))
+        shutil.copy(summ, os.path.join(root, "profiles", name + "_pmc_summary.json"))
+        if os.path.exists(d + "_bench.json") and os.path.getsize(d + "_bench.json"):
+            shutil.copy(d + "_bench.json", os.path.join(root, "profiles", name + "_bench.json"))
+        s = json.load(open(summ))
+        for k, cs in s["counters"].items():
+            # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
+            timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
+            if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                key = "config%d" % cfg if kind == "single" else "config%d_x16" % cfg
+                traffic[key] = {
+                    "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
+                    "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0,
+                    "launch": "one Render" if kind == "single" else "16 Renders",
+                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh %d %s, round tag %s" % (cfg, kind, tag)}
 json.dump(traffic, open(traffic_path, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
