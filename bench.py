@@ -135,12 +135,13 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
                            "ms_per_frame_extrapolated": dt1 * 1e3 * one_step}}
 
 
-def _traffic_from_profile(config):
+def _traffic_from_profile(config, frames_per_launch=1):
     """HBM bytes per launch of the trace kernel from the committed PMC pass (profiles/traffic.json), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
+    key = "config%d" % config + ("_x%d" % frames_per_launch if frames_per_launch > 1 else "")
     try:
         with open(p) as f:
-            return json.load(f).get("config%d" % config, {}).get("hbm_bytes_per_launch")
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -148,13 +149,15 @@ def _traffic_from_profile(config):
 TRAFFIC_SOURCE = "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of a rocprofv3 --pmc pass over this command, committed; not measured in this run"
 
 
-def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world):
+def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, profiling=False):
     """Price the trace kernel of the timed launches (cnt / kt: their counters and event times) against its bound."""
     px = cfg["w"] * cfg["h"]
     launches = max(kt.launches, 1)
     avg_kernel_s = kt.total_ms / launches / 1e3
     rays_per_launch = cnt.rays / launches
-    traffic = _traffic_from_profile(config_id)
+    frames_per_launch = max(1, round(len(frames) / launches))        # 1, or 16 under --profile throughput
+    px = px * frames_per_launch                                      # pixel-frames per launch
+    traffic = _traffic_from_profile(config_id, frames_per_launch)
     if cfg["mode"] == 1:
         flops = rays_per_launch * FLOPS_PER_SPHERE_RAY(len(scene.spheres)) + px * FLOPS_PER_PIXEL_RESOLVE
         achieved = flops / avg_kernel_s / 1e12
@@ -185,15 +188,16 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world):
     r.set_stats(False)
     # grazing ties: primary ids that differ between the reference walk order and front to back (one frame each, untimed)
     order_ties = None
-    if order_used != "reference" and world == 1:
+    if order_used != "reference" and world == 1 and not profiling:   # (a profiler pass keeps to launches of one kind)
         ids = {}
         for o in (1, 2):
             st.TraversalOrder = o; r.push_settings(); r.record_ids(True)
             r.render_only(1); ids[o] = r.read_primary_ids()
         r.record_ids(False)
         st.TraversalOrder = ORDERS[order_name]; r.push_settings()
-        order_ties = {"primary_ids_differing_from_reference_order": int((ids[1] != ids[2]).sum()), "pixels": int(px)}
-    per_launch = lambda v: v / max(len(frames), 1)
+        order_ties = {"primary_ids_differing_from_reference_order": int((ids[1] != ids[2]).sum()), "pixels": int(cfg["w"] * cfg["h"])}
+    per_launch = lambda v: v / launches              # the counting pass rendered the same frames once each
+    per_frame = lambda v: v / max(len(frames), 1)
     # what the trace kernel itself walked: the counters minus the part that stands for the column rays (primary rays with
     # direction.x == +0), which the pre-pass resolves without walking the tree ray by ray
     own_nodes = per_launch(c2.nodes_visited - c2.prepass_nodes)
@@ -210,10 +214,10 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world):
             "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
             "prepass_avg_ms": kt.prepass_total_ms / launches,
             "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
-            "column_rays_reference_equivalent": {"nodes_per_frame": per_launch(c2.prepass_nodes), "tris_per_frame": per_launch(c2.prepass_tris)},
+            "column_rays_reference_equivalent": {"nodes_per_frame": per_frame(c2.prepass_nodes), "tris_per_frame": per_frame(c2.prepass_tris)},
             "rays_per_launch": rays_per_launch, "traversal": order_used, "reference_order_counts": ref_counts,
             "grazing_ties": order_ties,
-            "near_tie_rewalks_per_frame": cnt.near_ties / launches,
+            "near_tie_rewalks_per_frame": per_frame(cnt.near_ties),
             "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per ray for the hit's "
                     "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
                     "that was timed; `frac` prices them against the HBM peak as the contract asks, `frac_hbm_moved` is what the PMC "
@@ -243,6 +247,32 @@ def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=Non
         out["roofline_frac"] = flops / (kernel_ms_per_frame / 1e3) / 1e12 / PEAK_VALU_NOFMA_TFLOPS
     elif bytes_per_frame:
         out["roofline_frac"] = bytes_per_frame / (kernel_ms_per_frame / 1e3) / 1e9 / PEAK_HBM_GBS
+    return out
+
+
+def first_hit_reuse(r, st, cfg, torch, steps, launches):
+    """Tree scenes with rt_settings.reuse_first_hits: the primary hit of every pixel is found once (the camera stands still
+    during an accumulation) and each Render starts its paths from it -- same frames bit for bit, but not the reference's
+    amount of work per Render, so it is reported beside the main figures and never in them.  `value` counts the reference's
+    TraceRay invocations (as everywhere); `traced_value` only the rays whose hit was searched for in these launches."""
+    st.ReuseFirstHits = True; r.push_settings()
+    out = {"note": "primary hits kept per pixel while camera, directions and tree are unchanged (found by one extra launch, "
+                   "outside the timed region like the other per-camera set-up); frames are bit-identical to those without it"}
+    for name, per, n in (("one_render_per_launch", 1, steps), ("throughput_mode", FRAMES_PER_LAUNCH, launches)):
+        r.reset_accum(); r.render_only(1001, per); r.sync(); torch.cuda.synchronize()
+        r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
+        t0 = time.perf_counter()
+        for i in range(n):
+            r.render_only(1 + i * per, per)
+        r.sync(); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        cnt, kt = r.read_counters(), r.kernel_time()
+        frames = n * per
+        out[name] = {"frames_per_launch": per, "launches": n, "ms_per_frame": dt / frames * 1e3, "value": cnt.rays / dt / 1e6,
+                     "traced_value": (cnt.rays - cnt.primary_hits_reused) / dt / 1e6, "unit": "Mrays/s",
+                     "kernel_ms_per_frame": kt.total_ms / max(kt.frames, 1), "rays_per_frame": cnt.rays / frames,
+                     "primary_hits_reused_per_frame": cnt.primary_hits_reused / frames}
+    st.ReuseFirstHits = False; r.push_settings()
     return out
 
 
@@ -295,6 +325,8 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
            "ms_per_step": dt / steps * 1e3, "rays_per_frame": cnt.rays / steps, "roofline": roof,
            "throughput_mode": throughput_mode(r, cfg, torch, max(1, steps // FRAMES_PER_LAUNCH), cnt.rays / steps,
                                               roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))}
+    if cfg["mode"] != 1:
+        rec["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, steps, max(1, steps // FRAMES_PER_LAUNCH))
     return rec, scene, cam, r
 
 
@@ -406,7 +438,7 @@ def main():
     kt = r.kernel_time()
 
     if rank == 0:
-        roof = roofline(args.config, cfg, scene, r, st, args.order, frames, cnt, kt, world)
+        roof = roofline(args.config, cfg, scene, r, st, args.order, frames, cnt, kt, world, bool(args.profile))
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
@@ -421,6 +453,8 @@ def main():
         if world == 1 and not use_dist and not args.profile:
             out["throughput_mode"] = throughput_mode(r, cfg, torch, max(1, K // FRAMES_PER_LAUNCH), rays_total / K,
                                                      roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))
+            if cfg["mode"] != 1:
+                out["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, K, max(1, K // FRAMES_PER_LAUNCH))
             out["with_d2h"] = with_d2h(r, torch, min(K, 32))
         if not args.no_cpu_baseline and world == 1:             # the CPU oracle is timed beside the one-GPU run only
             n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work

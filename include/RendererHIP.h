@@ -80,6 +80,8 @@ public:
         bool AntiAliasing = false;
         uint32_t Bounces = 8;
         int TraversalOrder = RT_ORDER_AUTO;    // not in the reference: KD tree walk order, see rt_mi355x.h
+        bool ReuseFirstHits = false;           // not in the reference: mesh scenes keep each pixel's primary hit while the camera stands still
+                                               // (same frames, bit for bit; rt_settings.reuse_first_hits)
         bool PipelinedHandoff = false;         // not in the reference: Render hands the frame over one call late while its
                                                // copy to the host runs beside the next trace (rt_map_image_pipelined)
     };
@@ -116,6 +118,7 @@ public:
         st.accumulate = m_settings.Accumulate; st.scene_mode = m_settings.UseSphereScene ? RT_SCENE_SPHERES : RT_SCENE_MESH;
         st.use_ace = m_settings.UseACE_Color; st.anti_aliasing = m_settings.AntiAliasing;
         st.bounces = m_settings.Bounces; st.seed = 1337; st.traversal = m_settings.TraversalOrder;
+        st.reuse_first_hits = m_settings.ReuseFirstHits;
 
         // spheres and materials are edited live by the UI (RaytracerApp.cpp:283-331): sent every frame (a few hundred bytes)
         m_spheres.resize(scene.spheres.size());

@@ -42,7 +42,12 @@ typedef struct { float albedo[3]; float emission[3]; float roughness, transparen
    (0 = mesh through the KD tree, 1 = spheres) and adds 2 = both, nearest wins by the strict sphere-first compare
    of Renderer.cpp:292-300.  `seed` seeds the per-(pixel, frame) pcg32 streams (the value Walnut::Random::Init
    intended, Random.h:22, is 1337).  `traversal` (no counterpart in the reference) selects the order in which the KD
-   tree is walked, see RT_ORDER_*. */
+   tree is walked, see RT_ORDER_*.  `reuse_first_hits` (no counterpart in the reference; 0 = off, the default): mesh scenes keep
+   the primary ray's closest triangle hit per pixel for as long as camera, directions, bands, tree and walk order stay as they
+   are, and every Render starts its paths from it instead of walking the tree for bounce 0 -- the ray and the tree are the
+   same and TraceRay draws no random number (Renderer.cpp:141-154,232-301), so every frame keeps its bits; the hits are found by
+   one extra launch (primary rays only) after any of those changed.  rt_counters.rays still counts those TraceRay invocations,
+   rt_counters.primary_hits_reused says how many of them were answered from the kept hits. */
 typedef struct {
     int32_t  accumulate;
     int32_t  scene_mode;
@@ -51,6 +56,7 @@ typedef struct {
     uint32_t bounces;
     uint32_t seed;
     int32_t  traversal;
+    int32_t  reuse_first_hits;
 } rt_settings;
 
 enum { RT_SCENE_MESH = 0, RT_SCENE_SPHERES = 1, RT_SCENE_BOTH = 2 };
@@ -95,8 +101,9 @@ typedef struct {
    direction.x == +0, which a per-frame pre-pass resolves without walking the tree ray by ray: they are what the
    reference's walk costs for those rays, not operations the GPU performed.  near_ties (always maintained): rays of the
    front-to-back walk that hit two different triangles within rounding distance of each other and were therefore walked
-   again in the reference's order (see rt_settings.traversal). */
-typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties; } rt_counters;
+   again in the reference's order (see rt_settings.traversal).  primary_hits_reused (always maintained): primary rays, part of
+   `rays`, whose hit came from the kept first hits (rt_settings.reuse_first_hits) instead of a walk. */
+typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties, primary_hits_reused; } rt_counters;
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh

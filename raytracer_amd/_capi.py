@@ -31,7 +31,8 @@ EXPORTS = [
 
 class RtSettings(C.Structure):
     _fields_ = [("accumulate", C.c_int32), ("scene_mode", C.c_int32), ("use_ace", C.c_int32),
-                ("anti_aliasing", C.c_int32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_int32)]
+                ("anti_aliasing", C.c_int32), ("bounces", C.c_uint32), ("seed", C.c_uint32), ("traversal", C.c_int32),
+                ("reuse_first_hits", C.c_int32)]
 
 
 class RtKdFlat(C.Structure):
@@ -42,7 +43,8 @@ class RtKdFlat(C.Structure):
 
 class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
-                ("sphere_tests", C.c_uint64), ("prepass_nodes", C.c_uint64), ("prepass_tris", C.c_uint64), ("near_ties", C.c_uint64)]
+                ("sphere_tests", C.c_uint64), ("prepass_nodes", C.c_uint64), ("prepass_tris", C.c_uint64), ("near_ties", C.c_uint64),
+                ("primary_hits_reused", C.c_uint64)]
 
 
 class RtKernelTime(C.Structure):

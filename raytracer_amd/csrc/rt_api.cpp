@@ -65,7 +65,7 @@ struct rt_ctx {
     std::string error;
 
     uint32_t width = 0, height = 0;
-    rt_settings settings{1, RT_SCENE_MESH, 1, 0, 8, 1337, RT_ORDER_AUTO};    // Renderer::Settings defaults (Renderer.h:103-110)
+    rt_settings settings{1, RT_SCENE_MESH, 1, 0, 8, 1337, RT_ORDER_AUTO, 0};    // Renderer::Settings defaults (Renderer.h:103-110)
     bool have_camera = false;
     float cam_pos[3]{}, inv_proj[16]{}, inv_view[16]{};
     uint32_t band_index = 0, band_count = 1;
@@ -85,6 +85,8 @@ struct rt_ctx {
     bool halo_complete = true;
     bool halo_in_columns = false;        // the column-ray numbering in d_dirs.w includes the halo rows
     bool column_cache = false;           // the pre-pass queue on the device belongs to the current camera, directions, bands and tree
+    DevBuf<float4> d_first_hits;         // rt_settings.reuse_first_hits: the primary ray's mesh hit per pixel ...
+    bool first_hits_valid = false;       // ... and whether it belongs to the current camera, directions, bands, tree and walk order
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
@@ -214,6 +216,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.park_keys = c->d_park_keys.ptr; p.park_boxes = c->d_park_boxes.ptr; p.park_queue = c->d_park_queue.ptr;
     p.park_queue_count = c->d_park_queue_count.ptr; p.park_queue_cap = rt_ctx::kParkQueueCap;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
+    p.first_hits = nullptr; p.first_hit_mode = 0u;
     p.slice_leave = c->n_nodes >= RT_LARGE_TREE ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
     for (int a = 0; a < 3; ++a) { p.root_center[a] = c->root_center[a]; p.tie_box[a] = c->tie_box[a]; }
     p.tie_ulp = c->tie_ulp; p.tie_rel = c->tie_rel; p.tie_abs = c->tie_abs;
@@ -318,7 +321,7 @@ rt_ctx* rt_create(int device_id)
         c->d_park_paths.resize(2 * (size_t)RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
-        c->d_column_stats.resize(3) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 24) != hipSuccess ||
+        c->d_column_stats.resize(4) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 32) != hipSuccess ||
         c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
         c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
         c->d_column_dirs.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_queue_count.resize(1) != hipSuccess ||
@@ -352,7 +355,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
-    c->d_slots.release(); c->d_image_back.release();
+    c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release();
     for (int i = 0; i < rt_ctx::UP_RING; ++i) {
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
         if (c->up_buf[i]) (void)hipHostFree(c->up_buf[i]);
@@ -391,6 +394,7 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
     // needs one returns RT_E_STATE, instead of kernels running over buffers of the wrong size
     c->width = 0; c->height = 0;
     c->d_slots.release(); c->slot_frames = 0; c->d_image_back.release(); c->latest_in_back = false;
+    c->d_first_hits.release(); c->first_hits_valid = false;
     for (int i = 0; i < 2; ++i) { if (c->h_image[i]) { (void)hipHostFree(c->h_image[i]); c->h_image[i] = nullptr; } c->h_image_pending[i] = false; }
     c->h_image_bytes = 0;
     hipError_t e = c->d_accum.resize(n);
@@ -404,7 +408,7 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
         c->d_accum.release(); c->d_image.release(); c->d_ids.release(); c->d_dirs.release();
         return fail(c, e == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_HIP, "rt_resize(%u, %u): %s", w, h, hipGetErrorString(e));
     }
-    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->halo_complete = true;
+    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->first_hits_valid = false; c->halo_complete = true;
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -414,6 +418,7 @@ int rt_set_settings(rt_ctx* c, const rt_settings* s)
     if (!c || !s) return RT_E_ARG;
     if (s->scene_mode < 0 || s->scene_mode > 2) return fail(c, RT_E_ARG, "scene_mode %d", s->scene_mode);
     if (s->traversal < RT_ORDER_AUTO || s->traversal > RT_ORDER_FRONT_TO_BACK) return fail(c, RT_E_ARG, "traversal %d", s->traversal);
+    if (s->scene_mode != c->settings.scene_mode || s->traversal != c->settings.traversal) c->first_hits_valid = false;
     c->settings = *s;
     return RT_OK;
 }
@@ -495,7 +500,7 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->n_tris = ntris; c->n_verts = nverts;
     c->n_nodes = 0; c->n_refs = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
-    c->column_cache = false;
+    c->column_cache = false; c->first_hits_valid = false;
     return RT_OK;
 }
 
@@ -710,7 +715,7 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             }
         }
     }
-    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false;
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false; c->first_hits_valid = false;
     return RT_OK;
 }
 
@@ -729,7 +734,7 @@ int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const
     if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
     // directions are regenerated only when the matrices change (Camera.cpp:96-100,113-114)
     if (!c->have_camera || memcmp(c->inv_proj, inv_proj, 64) != 0 || memcmp(c->inv_view, inv_view, 64) != 0) c->dirs_dirty = true;
-    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false;     // the column rays start at the camera
+    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false; c->first_hits_valid = false;     // the column rays start at the camera
     memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
     c->have_camera = true;
     return RT_OK;
@@ -781,7 +786,7 @@ int ensure_columns(rt_ctx* c, RtParams& p)
     }
     if (c->halo_in_columns != (p.halo != 0u)) c->columns_dirty = true;      // the rows bordering the bands joined or left the frame
     if (!c->columns_dirty) return RT_OK;
-    c->column_cache = false; c->halo_in_columns = p.halo != 0u;
+    c->column_cache = false; c->first_hits_valid = false; c->halo_in_columns = p.halo != 0u;
     HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -815,6 +820,47 @@ int trace_grid(rt_ctx* c, int mode, bool stats, bool ordered, uint32_t n_units, 
 
 namespace {
 
+// One launch of the trace kernel over the units of `p` and, in trees large enough for parking, the rounds that finish the paths
+// it parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a glass sphere that sits on
+// the camera's x).  Their hits by whole-chip kernels, family by family, then the rest of those paths by a small launch of the
+// trace kernel -- which may park again at a later bounce, into the other list: one round per bounce at most.  How many were
+// parked decides what is launched, so the host reads that one word back.  `stop`: event recorded right after the main launch.
+int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsigned grid, hipEvent_t stop)
+{
+    const bool tree = mode != RT_SCENE_SPHERES;
+    // With spheres and mesh together such rays are systematic (the centre column behind a sphere on the camera's x), so they are
+    // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
+    // the rare walk by a wave, except in large trees.
+    if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
+    const bool parking = tree && c->n_nodes >= p.park_min_nodes;
+    if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
+    // the unit tickets of tree scenes start at zero for every launch that draws units
+    if (tree) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
+    if (stop) HIP_TRY(c, hipEventRecord(stop, c->stream));
+    if (!parking) return RT_OK;
+    uint32_t parked = 0;
+    int cur = 0;
+    HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr, sizeof parked, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (uint32_t round = 0; parked != 0; ++round) {
+        const bool last = round + 1 >= c->settings.bounces;
+        RtParams q = p;
+        q.resume_count = c->d_park_count.ptr + cur; q.resume_paths = c->d_park_paths.ptr + (size_t)cur * RT_PARK_SLOTS * RT_PARK_WORDS;
+        q.park_count = c->d_park_count.ptr + (1 - cur); q.park_paths = c->d_park_paths.ptr + (size_t)(1 - cur) * RT_PARK_SLOTS * RT_PARK_WORDS;
+        HIP_TRY(c, hipMemsetAsync(q.park_count, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
+        q.resume = last ? 2u : 1u;
+        const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
+        HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
+        if (last) break;
+        cur = 1 - cur;
+        HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return RT_OK;
+}
+
 // Frames frame_index .. frame_index + n - 1 in one launch of the trace kernel (tree scenes: n <= RT_MAX_LAUNCH_FRAMES).
 int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
 {
@@ -845,11 +891,24 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     const bool ordered = tree && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units * (tree ? n : 1u), grid)) return rc;
-    // events: [pre, start) = the column pre-pass (mesh scenes whose camera has direction.x == +0 pixels), [start, stop) = the trace kernel
+    // rt_settings.reuse_first_hits: the primary ray of a pixel and its mesh hit are the same in every Render while camera,
+    // directions, bands, tree and walk order stay as they are (TraceRay draws no random number, Renderer.cpp:232-301).  A launch of
+    // the trace kernel that only traces the primary rays stores the hits when any of those changed; the Renders start from them.
+    // The counting kernels and the per-wave clocks describe full walks and never use it.
+    const bool reuse = tree && c->settings.reuse_first_hits && c->settings.bounces != 0u && !c->stats && !c->wave_clock_on;
+    const bool store_first = reuse && !c->first_hits_valid;
+    if (reuse && c->d_first_hits.count != (size_t)c->width * c->height) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        hipError_t e = c->d_first_hits.resize((size_t)c->width * c->height);
+        if (e != hipSuccess) return fail(c, RT_E_NOMEM, "first-hit buffer of %zu pixels: %s", (size_t)c->width * c->height, hipGetErrorString(e));
+    }
+    // events: [pre, start) = what precedes the trace kernel on mesh scenes (the column pre-pass when the camera has direction.x == +0
+    // pixels, the launch that stores first hits), [start, stop) = the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
-    c->ev_has_pre[ev] = tree && c->n_columns;
-    if (c->ev_has_pre[ev]) {
-        HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
+    const bool prepass = tree && c->n_columns && (!reuse || store_first);     // (stored hits answer the column rays too)
+    c->ev_has_pre[ev] = prepass || store_first;
+    if (c->ev_has_pre[ev]) HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
+    if (prepass) {
         // Which leaf records the column rays can hit depends on the camera, the directions and the tree only: found once and kept
         // (the queue of undecided (record, 16 rays) pairs); every launch repeats the triangle tests on that queue.  The counting
         // kernels always run the whole pre-pass: their counters describe what the reference's walk costs for these rays.
@@ -857,48 +916,23 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
         HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, cached ? 1 : 0, c->stream));
         c->column_cache = true;
     } else p.column_best = nullptr;
+    if (store_first) {
+        RtParams q = p;
+        q.n_frames = 1; q.first_hits = c->d_first_hits.ptr; q.first_hit_mode = 1u; q.primary_ids = nullptr;
+        unsigned grid1;
+        if (int rc = trace_grid(c, mode, false, ordered, q.n_units, grid1)) return rc;
+        if (int rc = trace_and_finish_parked(c, q, mode, ordered, grid1, nullptr)) return rc;
+        c->first_hits_valid = true;
+    }
+    if (reuse) { p.first_hits = c->d_first_hits.ptr; p.first_hit_mode = 2u; }
     // sphere frames resolve inside the trace kernel; the 3x3 filter needs the neighbours' sums and keeps the separate pass
     const bool fused = !tree && !c->settings.anti_aliasing;
     p.fuse_resolve = fused ? 1u : 0u;
     HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
-    // With spheres and mesh together such rays are systematic (the centre column behind a sphere on the camera's x), so they are
-    // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
-    // the rare walk by a wave, except in large trees.
-    if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
-    const bool parking = tree && c->n_nodes >= p.park_min_nodes;
-    if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
-    // the unit tickets of tree scenes start at zero for every launch that draws units
-    if (tree) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
-    HIP_TRY(c, hipEventRecord(c->ev_stop[ev], c->stream));
+    if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, c->ev_stop[ev])) return rc;
     c->ev_frames[ev] = n;
     c->ev_head++;
-    if (parking) {
-        // The paths the launch parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a
-        // glass sphere that sits on the camera's x).  Their hits by whole-chip kernels, family by family, then the rest of those
-        // paths by a small launch of the trace kernel -- which may park again at a later bounce, into the other list: one round
-        // per bounce at most.  How many were parked decides what is launched, so the host reads that one word back.
-        uint32_t parked = 0;
-        int cur = 0;
-        HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr, sizeof parked, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        for (uint32_t round = 0; parked != 0; ++round) {
-            const bool last = round + 1 >= c->settings.bounces;
-            RtParams q = p;
-            q.resume_count = c->d_park_count.ptr + cur; q.resume_paths = c->d_park_paths.ptr + (size_t)cur * RT_PARK_SLOTS * RT_PARK_WORDS;
-            q.park_count = c->d_park_count.ptr + (1 - cur); q.park_paths = c->d_park_paths.ptr + (size_t)(1 - cur) * RT_PARK_SLOTS * RT_PARK_WORDS;
-            HIP_TRY(c, hipMemsetAsync(q.park_count, 0, sizeof(uint32_t), c->stream));
-            HIP_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
-            q.resume = last ? 2u : 1u;
-            const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
-            HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
-            if (last) break;
-            cur = 1 - cur;
-            HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-    }
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
     if (tree) HIP_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
@@ -1095,9 +1129,9 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     for (size_t i = 0; i < h.size(); i += 4) {
         out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
     }
-    unsigned long long cs[3] = {0, 0, 0};
+    unsigned long long cs[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
-    out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2];
+    out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2]; out->primary_hits_reused = cs[3];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
     return RT_OK;
 }
@@ -1108,7 +1142,7 @@ int rt_reset_counters(rt_ctx* c)
     if (!c->d_counters.count) return RT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 3 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 4 * sizeof(unsigned long long), c->stream));
     return RT_OK;
 }
 

@@ -4,12 +4,14 @@
 //
 //   rt_bench [--config 1|2|3|4|5] [--width W --height H --bounces B --mode 0|1|2 --grid N --scale S]
 //            [--frames K] [--warmup W] [--frames-per-launch F] [--d2h 0|1|2] [--devices 0,1,...] [--split tiles|samples]
+//            [--reuse-first-hits 0|1]
 //
 // --config picks one of the five benchmark configurations (default 2: the default sphere scene at 1920x1080, 5 bounces);
 // the other options override it.  --d2h 1 ends every Render with the frame in host memory (rt_map_image), as
 // Renderer::Render does (Renderer.cpp:134); 2 = the pipelined hand-off; 0 (default) leaves frames in HBM.
 // --devices lists the GPUs of a group (a device may be repeated); --split tiles (one frame over all GPUs, default) or
-// samples (every GPU its own frame indices).  Prints one JSON line: ms per frame (wall clock around the Render calls,
+// samples (every GPU its own frame indices).  --reuse-first-hits 1 sets rt_settings.reuse_first_hits (mesh scenes keep each
+// pixel's primary hit while the camera stands still).  Prints one JSON line: ms per frame (wall clock around the Render calls,
 // what the reference shows as "Last render"), Mrays/s from the device's ray counter, trace-kernel ms from HIP events.
 #include <chrono>
 #include <cmath>
@@ -35,6 +37,7 @@ struct Options {
     int d2h = 0;
     std::vector<int> devices{0};
     bool samples = false;
+    int reuse_first_hits = 0;
 };
 
 void preset(Options& o, int config)
@@ -126,6 +129,7 @@ int main(int argc, char** argv)
         else if (a == "--frames-per-launch") o.per_launch = (uint32_t)atoi(val());
         else if (a == "--d2h") o.d2h = atoi(val());
         else if (a == "--split") o.samples = !strcmp(val(), "samples");
+        else if (a == "--reuse-first-hits") o.reuse_first_hits = atoi(val()) != 0;
         else if (a == "--devices") {
             o.devices.clear();
             for (const char* p = val(); *p;) { o.devices.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
@@ -156,7 +160,7 @@ int main(int argc, char** argv)
 
     rt_group* g = rt_group_create(o.devices.data(), (int)n_dev);
     if (!g) die("rt_group_create", rt_last_error(nullptr));
-    rt_settings st{1, o.mode, 1, 0, o.bounces, 1337, RT_ORDER_AUTO};
+    rt_settings st{1, o.mode, 1, 0, o.bounces, 1337, RT_ORDER_AUTO, o.reuse_first_hits};
     auto upload = [&]() {                          // what Renderer::Render reads from Scene and Camera, every frame
         for (uint32_t i = 0; i < n_dev; ++i) {
             rt_ctx* c = rt_group_ctx(g, (int)i);
@@ -198,19 +202,19 @@ int main(int argc, char** argv)
     sync_all();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-    uint64_t rays = 0; double kernel_ms = 0.0; uint64_t kframes = 0;
+    uint64_t rays = 0, reused = 0; double kernel_ms = 0.0; uint64_t kframes = 0;
     for (uint32_t i = 0; i < n_dev; ++i) {
         rt_counters cnt; rt_kernel_time kt;
         if (rt_read_counters(rt_group_ctx(g, (int)i), &cnt) || rt_get_kernel_time(rt_group_ctx(g, (int)i), &kt)) die("counters", rt_last_error(rt_group_ctx(g, (int)i)));
-        rays += cnt.rays; if (i == 0) { kernel_ms = kt.total_ms; kframes = kt.frames; }
+        rays += cnt.rays; reused += cnt.primary_hits_reused; if (i == 0) { kernel_ms = kt.total_ms; kframes = kt.frames; }
     }
     printf("{\"bench\": \"rt_bench (C++ host, headless)\", \"config\": %d, \"width\": %u, \"height\": %u, \"bounces\": %u, \"scene_mode\": %d, "
            "\"triangles\": %zu, \"kd_nodes\": %u, \"kd_depth\": %u, \"kd_build_s\": %.2f, \"devices\": %u, \"split\": \"%s\", "
            "\"frames\": %u, \"frames_per_launch\": %u, \"d2h\": %d, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"rays_per_frame\": %.0f, "
-           "\"trace_kernel_ms_per_frame_gpu0\": %.4f}\n",
+           "\"trace_kernel_ms_per_frame_gpu0\": %.4f, \"reuse_first_hits\": %d, \"primary_hits_reused_per_frame\": %.0f}\n",
            o.config, o.width, o.height, o.bounces, o.mode, mesh.tris.size() / 3, flat.n_nodes, depth, build_s, n_dev,
            n_dev == 1 ? "none" : (o.samples ? "samples" : "tiles"), made, o.per_launch, o.d2h, dt / made * 1e3, (double)rays / dt / 1e6,
-           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0);
+           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0, o.reuse_first_hits, (double)reused / made);
     rt_group_destroy(g);
     if (kd) rt_host_kd_free(kd);
     return 0;

@@ -130,11 +130,17 @@ struct RtParams {
     float4* slots;                          // tree scenes: n_frames planes of width*height { radiance.rgb, walk steps } -- the value each
                                             // Render of the launch adds to its pixel, summed into `accum` in frame order by the resolve pass
     int32_t* primary_ids;                   // optional
+    // Tree scenes, optional: the primary ray of a pixel (Renderer.cpp:141-143,154 at bounce 0) is the same in every Render while
+    // camera, directions and tree stay as they are, and TraceRay draws no random number, so its hit can be kept per pixel.
+    // first_hit_mode 1: trace only the primary rays and store their mesh hits { t, u, v, bits(triangle id) } (no shading, no
+    // radiance); 2: every path starts from the stored hit instead of walking the tree for bounce 0; 0: off.
+    float4*  first_hits;
+    uint32_t first_hit_mode;
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop
-    unsigned long long* column_stats;       // 3: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
-                                            // reference's order because of a near tie
+    unsigned long long* column_stats;       // 4: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
+                                            // reference's order because of a near tie; primary rays answered from first_hits
     // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records
     uint32_t  column_cap;

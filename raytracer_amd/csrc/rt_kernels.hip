@@ -1609,7 +1609,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     const bool sharing = SHARE && p.resume == 0u;           // a resume launch only finishes the parked paths
     bool waiting = false;                                   // wave-uniform: this wave is counted in pool.hungry, not in pool.busy
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
-    uint32_t n_rays = 0, n_nodes = 0, n_tris = 0;
+    uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, n_reused = 0;
     unsigned long long clock_start = 0, trips = 0, lane_trips = 0, walk_ticks = 0; uint32_t n_iterations = 0;
     const bool clocked = p.wave_clock != nullptr && !p.resume;
     if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
@@ -1753,8 +1753,15 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             bool start = begin && s.bounce < p.bounces;     // else "for (i = 0; i < Bounces; i++)" with Bounces == 0: ends below
             bool have_hit = false;
             if (start) { th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f; }
+            // the primary ray's hit is known from an earlier launch (RtParams::first_hits)
+            if (start && s.bounce == 0u && p.first_hit_mode == 2u) {
+                const float4 h = p.first_hits[pixel];
+                th.t = h.x; th.u = h.y; th.v = h.z; th.id = (int32_t)__float_as_uint(h.w);
+                have_hit = true;
+                n_reused++;
+            }
             // rays the tree cannot prune (direction.x == 0): answered by the pre-pass, by the whole-chip kernels, or by this wave
-            bool unprunable = start && s.D.x == 0.0f;
+            bool unprunable = start && !have_hit && s.D.x == 0.0f;
             if (unprunable && s.bounce == 0 && s.column_slot != 0u && p.column_best && (*p.column_flags & 1u) == 0u) {
                 // primary column rays were resolved for the whole frame by the pre-pass: re-run the winning triangle test for u, v
                 const unsigned long long key = p.column_best[s.column_slot - 1u];
@@ -1815,9 +1822,9 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             }
             if (start) {
                 s.bounce++;
-                n_rays++;
+                if (p.first_hit_mode != 1u) n_rays++;       // (the launch that only stores primary hits is not a Render: its rays are counted by the launches that use them)
                 tS = FLT_MAX; iS = -1;
-                if (MODE == RT_MODE_BOTH) trace_spheres(p, s.O, s.D, tS, iS);
+                if (MODE == RT_MODE_BOTH && p.first_hit_mode != 1u) trace_spheres(p, s.O, s.D, tS, iS);
                 if (have_hit || end == 0u) phase = PH_SHADE;
                 else {
                     winvD = f3(1.0f / s.D.x, 1.0f / s.D.y, 1.0f / s.D.z);          // Renderer.cpp:151
@@ -1960,7 +1967,12 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         }
 
         // ---- the lanes whose ray is traced: the rest of the bounce (Renderer.cpp:160-226)
-        if (phase == PH_SHADE) {
+        if (phase == PH_SHADE && p.first_hit_mode == 1u) {
+            // only the primary ray's mesh hit is wanted: kept for the launches that follow
+            if (p.bounces != 0u) p.first_hits[pixel] = make_float4(th.t, th.u, th.v, __uint_as_float((uint32_t)th.id));
+            wsteps = 0;
+            phase = PH_IDLE;
+        } else if (phase == PH_SHADE) {
             int32_t* id_out = (p.primary_ids && frame == 0) ? p.primary_ids + pixel : nullptr;
             bool ended = true;
             if (p.bounces != 0u) ended = shade_hit<MODE, false>(s, p, lds, id_out, s.bounce == 1u, s.bounce >= p.bounces, tS, iS, th);
@@ -1988,10 +2000,11 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
         unsigned long long* slot = p.counters + 4 * (size_t)wave;
-        uint32_t r = n_rays, n = n_nodes, t = n_tris;
+        uint32_t r = n_rays, n = n_nodes, t = n_tris, u = n_reused;
         for (int off = 32; off > 0; off >>= 1) {
-            r += __shfl_down(r, off); n += __shfl_down(n, off); t += __shfl_down(t, off);
+            r += __shfl_down(r, off); n += __shfl_down(n, off); t += __shfl_down(t, off); u += __shfl_down(u, off);
         }
+        if (lane == 0 && u != 0u) atomicAdd(p.column_stats + 3, (unsigned long long)u);
         if (lane == 0) {
             slot[0] += (unsigned long long)r;
             if (STATS) { slot[1] += (unsigned long long)n; slot[2] += (unsigned long long)t; }

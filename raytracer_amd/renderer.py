@@ -19,7 +19,8 @@ from .scenes import MATERIAL_DTYPE, SPHERE_DTYPE
 class Settings:
     """Renderer::Settings (Renderer.h:103-110).  `SceneMode` (None = follow UseSphereScene) selects the added
     spheres+mesh mode; `Seed` seeds the per-(pixel, frame) random streams; `TraversalOrder` is the KD tree walk
-    order (_capi.ORDER_AUTO / ORDER_REFERENCE / ORDER_FRONT_TO_BACK, see include/rt_mi355x.h)."""
+    order (_capi.ORDER_AUTO / ORDER_REFERENCE / ORDER_FRONT_TO_BACK, see include/rt_mi355x.h); `ReuseFirstHits` makes mesh scenes
+    keep each pixel's primary hit while camera and tree stay as they are (rt_settings.reuse_first_hits: same frames, bit for bit)."""
 
     def __init__(self):
         self.Render = True
@@ -31,6 +32,7 @@ class Settings:
         self.SceneMode = None
         self.Seed = 1337
         self.TraversalOrder = _capi.ORDER_AUTO
+        self.ReuseFirstHits = False
 
     def scene_mode(self):
         if self.SceneMode is not None:
@@ -39,7 +41,8 @@ class Settings:
 
     def to_c(self):
         return RtSettings(int(bool(self.Accumulate)), self.scene_mode(), int(bool(self.UseACE_Color)),
-                          int(bool(self.AntiAliasing)), int(self.Bounces), int(self.Seed), int(self.TraversalOrder))
+                          int(bool(self.AntiAliasing)), int(self.Bounces), int(self.Seed), int(self.TraversalOrder),
+                          int(bool(self.ReuseFirstHits)))
 
 
 class KDTree:

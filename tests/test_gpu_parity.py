@@ -56,13 +56,13 @@ ORDERS = [pytest.param(REF_ORDER, id="reference-order"), pytest.param(F2B_ORDER,
 
 
 def run_both(rt, orc, r, scene, osc, w, h, mode, bounces, frames, use_ace=True, aa=False, seed=1337, stats=False,
-             cam=None, threads=8, order=0):
+             cam=None, threads=8, order=0, reuse=False):
     if cam is None:
         cam = rt.Camera(70.0, 0.05, 100.0)
     cam.OnResize(w, h)
     st = r.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, bounces, use_ace, aa, True, seed
-    st.TraversalOrder = order
+    st.TraversalOrder, st.ReuseFirstHits = order, reuse
     r.OnResize(w, h)
     r.ResetFrameIndex()
     r.record_ids(True)
@@ -80,7 +80,7 @@ def run_both(rt, orc, r, scene, osc, w, h, mode, bounces, frames, use_ace=True, 
                cnt=r.read_counters())
     want = dict(ids=ids, acc=acc, img=img, cnt=cnt)
     r.set_stats(False)
-    st.TraversalOrder = 0
+    st.TraversalOrder, st.ReuseFirstHits = 0, False
     return got, want
 
 
@@ -810,6 +810,64 @@ def test_centre_column_through_the_glass_sphere_parks_whole_families(rt, orc, pa
     assert_exact(got, want)
     col = want["ids"].reshape(160, 96)[:, 48]
     assert (col == 7).sum() > 20                           # the centre column sees the glass sphere (index 7)
+
+
+@pytest.mark.parametrize("order", ORDERS)
+@pytest.mark.parametrize("mode", [0, 2], ids=["mesh", "spheres+mesh"])
+def test_first_hit_reuse_keeps_every_bit(rt, orc, renderer, parking_renderer, mode, order):
+    """rt_settings.reuse_first_hits: the primary ray's mesh hit is found once per pixel (a launch that traces primary rays only) and
+    every Render starts from it.  Ids, accumulation, image and ray count against the oracle, bit-exact: three single Renders
+    (every primary ray answered from the kept hits), then 21 Renders in one call (launches of 16 and 5) against a context that
+    walks every primary ray, then a moved camera (the kept hits are dropped and found again), then the same through the parking
+    path (the default camera's centre column has direction.x == +0: pre-pass, parked rays and kept hits together)."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(28), spheres=mode == 2)
+    w, h = 96, 160
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, mode, 8, 3, order=order, reuse=True)
+    assert_exact(got, want)
+    assert got["cnt"].primary_hits_reused == 3 * w * h
+    # deeper, several Renders per launch: against the same context walking every primary ray
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings()
+    out = {}
+    for reuse in (False, True):
+        st.SceneMode, st.Bounces, st.TraversalOrder, st.ReuseFirstHits = mode, 8, order, reuse
+        renderer.ResetFrameIndex(); renderer.reset_counters()
+        renderer.Render(scene, cam, frames=21)
+        out[reuse] = (renderer.read_accum().copy(), renderer.GetImage().data.copy(), renderer.read_counters())
+    st.TraversalOrder, st.ReuseFirstHits = 0, False
+    assert np.array_equal(bits(out[True][0]), bits(out[False][0])) and np.array_equal(bits(out[True][1]), bits(out[False][1]))
+    assert out[True][2].rays == out[False][2].rays
+    assert out[True][2].primary_hits_reused == 21 * w * h and out[False][2].primary_hits_reused == 0
+    # another viewpoint: the hits kept for the first camera must not survive
+    cam2 = rt.Camera(70.0, 0.05, 100.0)
+    fwd = np.array([-0.2, -0.35, -1.0], np.float32); fwd /= np.linalg.norm(fwd)
+    cam2.SetPose(np.array([0.4, 1.3, 2.2], np.float32), fwd.astype(np.float32))
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, mode, 8, 2, cam=cam2, order=order, reuse=True)
+    assert_exact(got, want)
+    # with parking in this small tree
+    got, want = run_both(rt, orc, parking_renderer, scene, osc, w, h, mode, 8, 2, order=order, reuse=True)
+    assert_exact(got, want)
+
+
+def test_first_hit_reuse_under_a_tile_split_with_the_filter(rt, orc, renderer):
+    """Kept first hits with bands and the rows bordering them (3x3 filter under a tile split): three band contexts, two Renders
+    each, assembled image and accumulation against the oracle's filtered frame."""
+    from raytracer_amd import dist as rtd, scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(24, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0))
+    w, h = 150, 100
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 2, 5, 2, aa=True)
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    img = np.zeros((h, w, 4), np.float32); acc = np.zeros((h, w, 3), np.float32)
+    for rank in range(3):
+        rr = rt.Renderer(0)
+        s = rr.GetSettings(); s.SceneMode, s.Bounces, s.AntiAliasing, s.ReuseFirstHits = 2, 5, True, True
+        rr.OnResize(w, h); rr.set_bands(rank, 3)
+        rr.Render(scene, cam); rr.Render(scene, cam)
+        rows = rtd.band_rows(h, rank, 3)
+        img[rows] = rr.GetImage().data[rows]; acc[rows] = rr.read_accum()[rows]
+    assert np.array_equal(bits(acc.reshape(-1, 3)), bits(want["acc"]))
+    assert np.array_equal(bits(img.reshape(-1, 4)), bits(want["img"]))
 
 
 @pytest.mark.parametrize("order", ORDERS)
