@@ -102,8 +102,12 @@ typedef struct {
    reference's walk costs for those rays, not operations the GPU performed.  near_ties (always maintained): rays of the
    front-to-back walk that hit two different triangles within rounding distance of each other and were therefore walked
    again in the reference's order (see rt_settings.traversal).  primary_hits_reused (always maintained): primary rays, part of
-   `rays`, whose hit came from the kept first hits (rt_settings.reuse_first_hits) instead of a walk. */
-typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties, primary_hits_reused; } rt_counters;
+   `rays`, whose hit came from the kept first hits (rt_settings.reuse_first_hits) instead of a walk.  empty_unit_rays (always
+   maintained): primary rays, part of `rays`, of 16-pixel work units none of whose primary rays enters the tree's root box -- in a
+   scene without spheres those paths end in Miss() with a colour of zero (Renderer.cpp:160-165) and are not traced at all (found
+   once per camera, directions, bands and tree; the counting mode of rt_set_stats traces them like any other). */
+typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties, primary_hits_reused,
+                 empty_unit_rays; } rt_counters;
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh

@@ -24,6 +24,7 @@ extern "C" unsigned rt_trace_block(int mode);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int cached, hipStream_t s);
+extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s);
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
@@ -87,6 +88,12 @@ struct rt_ctx {
     bool column_cache = false;           // the pre-pass queue on the device belongs to the current camera, directions, bands and tree
     DevBuf<float4> d_first_hits;         // rt_settings.reuse_first_hits: the primary ray's mesh hit per pixel ...
     bool first_hits_valid = false;       // ... and whether it belongs to the current camera, directions, bands, tree and walk order
+    // mesh-only scenes: the work units in which a primary ray can hit anything (the others are not traced, see RtParams::unit_list)
+    DevBuf<unsigned char> d_unit_empty;
+    DevBuf<uint32_t> d_unit_list, d_unit_counts;
+    bool units_valid = false;            // they belong to the current camera, directions, bands and tree
+    uint32_t n_list = 0, empty_pixels = 0;
+    unsigned long long host_rays = 0;    // primary rays of empty units: TraceRay invocations that needed no kernel
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
@@ -356,6 +363,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
     c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release();
+    c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release();
     for (int i = 0; i < rt_ctx::UP_RING; ++i) {
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
         if (c->up_buf[i]) (void)hipHostFree(c->up_buf[i]);
@@ -408,7 +416,7 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
         c->d_accum.release(); c->d_image.release(); c->d_ids.release(); c->d_dirs.release();
         return fail(c, e == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_HIP, "rt_resize(%u, %u): %s", w, h, hipGetErrorString(e));
     }
-    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->first_hits_valid = false; c->halo_complete = true;
+    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_complete = true;
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -500,7 +508,7 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->n_tris = ntris; c->n_verts = nverts;
     c->n_nodes = 0; c->n_refs = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
-    c->column_cache = false; c->first_hits_valid = false;
+    c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;
     return RT_OK;
 }
 
@@ -715,7 +723,7 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             }
         }
     }
-    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false; c->first_hits_valid = false;
+    c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;
     return RT_OK;
 }
 
@@ -734,7 +742,7 @@ int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const
     if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
     // directions are regenerated only when the matrices change (Camera.cpp:96-100,113-114)
     if (!c->have_camera || memcmp(c->inv_proj, inv_proj, 64) != 0 || memcmp(c->inv_view, inv_view, 64) != 0) c->dirs_dirty = true;
-    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false; c->first_hits_valid = false;     // the column rays start at the camera
+    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;     // the column rays start at the camera
     memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
     c->have_camera = true;
     return RT_OK;
@@ -786,11 +794,35 @@ int ensure_columns(rt_ctx* c, RtParams& p)
     }
     if (c->halo_in_columns != (p.halo != 0u)) c->columns_dirty = true;      // the rows bordering the bands joined or left the frame
     if (!c->columns_dirty) return RT_OK;
-    c->column_cache = false; c->first_hits_valid = false; c->halo_in_columns = p.halo != 0u;
+    c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_in_columns = p.halo != 0u;
     HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->columns_dirty = false;
+    return RT_OK;
+}
+
+// Mesh-only scenes: which work units hold a primary ray that enters the root box (RtParams::unit_list); the two counts are read
+// back once per change, like the column count.
+int ensure_units(rt_ctx* c, RtParams& p)
+{
+    if (!c->units_valid) {
+        if (c->d_unit_empty.count < p.n_units) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->d_unit_empty.resize(p.n_units));
+            HIP_TRY(c, c->d_unit_list.resize(p.n_units));
+        }
+        if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(2));
+        p.unit_empty_out = c->d_unit_empty.ptr; p.unit_list_out = c->d_unit_list.ptr; p.unit_counts_out = c->d_unit_counts.ptr;
+        HIP_TRY(c, hipMemsetAsync(c->d_unit_counts.ptr, 0, 2 * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, rt_launch_units_classify(&p, c->stream));
+        uint32_t counts[2] = {0, 0};
+        HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr, sizeof counts, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->n_list = counts[0]; c->empty_pixels = counts[1];
+        c->units_valid = true;
+    }
+    p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr;
     return RT_OK;
 }
 
@@ -889,8 +921,12 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (int rc = ensure_dirs(c, p)) return rc;
     if (tree) { if (int rc = ensure_columns(c, p)) return rc; }
     const bool ordered = tree && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
+    // Units without a primary ray into the root box are not traced (a scene without spheres; the counting kernels trace all)
+    const bool skip_empty = mode == RT_SCENE_MESH && c->settings.bounces != 0u && !c->stats;
+    if (skip_empty) { if (int rc = ensure_units(c, p)) return rc; }
+    const uint32_t n_traced_units = skip_empty ? p.n_list : p.n_units;
     unsigned grid;
-    if (int rc = trace_grid(c, mode, c->stats, ordered, p.n_units * (tree ? n : 1u), grid)) return rc;
+    if (int rc = trace_grid(c, mode, c->stats, ordered, n_traced_units * (tree ? n : 1u), grid)) return rc;
     // rt_settings.reuse_first_hits: the primary ray of a pixel and its mesh hit are the same in every Render while camera,
     // directions, bands, tree and walk order stay as they are (TraceRay draws no random number, Renderer.cpp:232-301).  A launch of
     // the trace kernel that only traces the primary rays stores the hits when any of those changed; the Renders start from them.
@@ -920,7 +956,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
         RtParams q = p;
         q.n_frames = 1; q.first_hits = c->d_first_hits.ptr; q.first_hit_mode = 1u; q.primary_ids = nullptr;
         unsigned grid1;
-        if (int rc = trace_grid(c, mode, false, ordered, q.n_units, grid1)) return rc;
+        if (int rc = trace_grid(c, mode, false, ordered, n_traced_units, grid1)) return rc;
         if (int rc = trace_and_finish_parked(c, q, mode, ordered, grid1, nullptr)) return rc;
         c->first_hits_valid = true;
     }
@@ -933,6 +969,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, c->ev_stop[ev])) return rc;
     c->ev_frames[ev] = n;
     c->ev_head++;
+    if (skip_empty) c->host_rays += (unsigned long long)c->empty_pixels * n;
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
     if (tree) HIP_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
@@ -1133,6 +1170,7 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
     out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2]; out->primary_hits_reused = cs[3];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
+    out->rays += c->host_rays; out->empty_unit_rays = c->host_rays;
     return RT_OK;
 }
 
@@ -1143,6 +1181,7 @@ int rt_reset_counters(rt_ctx* c)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 4 * sizeof(unsigned long long), c->stream));
+    c->host_rays = 0;
     return RT_OK;
 }
 

@@ -202,19 +202,19 @@ int main(int argc, char** argv)
     sync_all();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-    uint64_t rays = 0, reused = 0; double kernel_ms = 0.0; uint64_t kframes = 0;
+    uint64_t rays = 0, reused = 0, skipped = 0; double kernel_ms = 0.0; uint64_t kframes = 0;
     for (uint32_t i = 0; i < n_dev; ++i) {
         rt_counters cnt; rt_kernel_time kt;
         if (rt_read_counters(rt_group_ctx(g, (int)i), &cnt) || rt_get_kernel_time(rt_group_ctx(g, (int)i), &kt)) die("counters", rt_last_error(rt_group_ctx(g, (int)i)));
-        rays += cnt.rays; reused += cnt.primary_hits_reused; if (i == 0) { kernel_ms = kt.total_ms; kframes = kt.frames; }
+        rays += cnt.rays; reused += cnt.primary_hits_reused; skipped += cnt.empty_unit_rays; if (i == 0) { kernel_ms = kt.total_ms; kframes = kt.frames; }
     }
     printf("{\"bench\": \"rt_bench (C++ host, headless)\", \"config\": %d, \"width\": %u, \"height\": %u, \"bounces\": %u, \"scene_mode\": %d, "
            "\"triangles\": %zu, \"kd_nodes\": %u, \"kd_depth\": %u, \"kd_build_s\": %.2f, \"devices\": %u, \"split\": \"%s\", "
            "\"frames\": %u, \"frames_per_launch\": %u, \"d2h\": %d, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"rays_per_frame\": %.0f, "
-           "\"trace_kernel_ms_per_frame_gpu0\": %.4f, \"reuse_first_hits\": %d, \"primary_hits_reused_per_frame\": %.0f}\n",
+           "\"trace_kernel_ms_per_frame_gpu0\": %.4f, \"reuse_first_hits\": %d, \"primary_hits_reused_per_frame\": %.0f, \"empty_unit_rays_per_frame\": %.0f}\n",
            o.config, o.width, o.height, o.bounces, o.mode, mesh.tris.size() / 3, flat.n_nodes, depth, build_s, n_dev,
            n_dev == 1 ? "none" : (o.samples ? "samples" : "tiles"), made, o.per_launch, o.d2h, dt / made * 1e3, (double)rays / dt / 1e6,
-           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0, o.reuse_first_hits, (double)reused / made);
+           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0, o.reuse_first_hits, (double)reused / made, (double)skipped / made);
     rt_group_destroy(g);
     if (kd) rt_host_kd_free(kd);
     return 0;

@@ -136,6 +136,15 @@ struct RtParams {
     // radiance); 2: every path starts from the stored hit instead of walking the tree for bounce 0; 0: off.
     float4*  first_hits;
     uint32_t first_hit_mode;
+    // Mesh-only scenes, optional: work units none of whose primary rays enters the root box ("empty": their paths end in
+    // Miss() with a colour of 0 + 1 * 0, Renderer.cpp:160-165).  Found when camera, directions, bands or tree change; the trace
+    // kernel then draws its tickets over unit_list (the n_list other units, ascending) and the resolve pass takes a radiance of
+    // zero for the units marked in unit_empty.  unit_out: where the classification writes (unit_empty, list, {n_list, pixels
+    // of empty units}).
+    const uint32_t* unit_list;
+    uint32_t n_list;
+    const unsigned char* unit_empty;
+    unsigned char* unit_empty_out; uint32_t* unit_list_out; uint32_t* unit_counts_out;
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop

@@ -1396,8 +1396,16 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 // A launch of n_frames Renders hands out (unit, frame) pairs: head h owns units h, h + 8, ... and its ticket t is frame t % n_frames
 // of unit h + 8 (t / n_frames), so the tickets of one refill are consecutive frames of the same pixels: their primary rays are
 // the same ray and walk the same nodes side by side.
-__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h) { return ((p.n_units + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS) * p.n_frames; }
-__device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t) { return h + RT_WORK_HEADS * (t / p.n_frames); }
+__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h)
+{
+    const uint32_t n = p.unit_list ? p.n_list : p.n_units;
+    return ((n + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS) * p.n_frames;
+}
+__device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t)
+{
+    const uint32_t i = h + RT_WORK_HEADS * (t / p.n_frames);
+    return p.unit_list ? p.unit_list[i] : i;                // (only the units in which a primary ray can hit anything, see RtParams::unit_list)
+}
 
 template <bool STATS, bool LDS_SCENE>
 __device__ __forceinline__ void sphere_body(const RtParams& p)
@@ -2041,13 +2049,62 @@ __global__ __launch_bounds__(256) void rt_sum_resolve_kernel(RtParams p, uint32_
     F3 acc = f3(0.0f, 0.0f, 0.0f);
     if (p.frame_first != 1u) { const float4 a = p.accum[pixel]; acc = f3(a.x, a.y, a.z); }
     float steps = 0.0f;
+    const bool empty = p.unit_empty && p.unit_empty[unit] != 0;        // no path was traced: each Render adds Miss()'s colour of zero
+    if (empty && p.primary_ids) p.primary_ids[pixel] = -1;
     for (uint32_t f = 0; f < p.n_frames; ++f) {
-        const float4 c = p.slots[(size_t)f * plane + pixel];
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!empty) c = p.slots[(size_t)f * plane + pixel];
         acc = acc + f3(c.x, c.y, c.z);
         steps = c.w;
     }
     p.accum[pixel] = make_float4(acc.x, acc.y, acc.z, steps);
     if (write_image && unit < p.n_units_main) p.image[pixel] = resolve_px(acc, (float)frame_index, p.use_ace);
+}
+
+// Which work units are empty (RtParams::unit_list): sixteen lanes per unit, one per pixel.  A unit is empty when every pixel of
+// it that lies in the frame has a primary ray with direction.x != 0 (the others take the column pre-pass) that fails the root
+// node's test exactly as the walk's first step would (slab_test, "descend" in tree_body).
+__global__ __launch_bounds__(256) void rt_units_classify_kernel(RtParams p)
+{
+    const uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    uint32_t pixel = 0;
+    const bool in_frame = unit < p.n_units && unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel);
+    bool live = false;                                      // this pixel's primary ray has to be traced
+    if (in_frame) {
+        const float4 d = p.dirs[pixel];
+        float tNear = 0.0f;
+        live = d.x == 0.0f || (slab_test(p.nodes[0], p.nodes[1], f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]),
+                                         f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tNear) && !(tNear > FLT_MAX));
+    }
+    const uint32_t group = (threadIdx.x & 63u) / RT_UNIT;
+    const unsigned long long mask = 0xFFFFull << (RT_UNIT * group);
+    static_assert(RT_UNIT == 16, "sixteen lanes per unit");
+    const bool empty = (__ballot(live) & mask) == 0ull;
+    const uint32_t pixels = (uint32_t)__popcll(__ballot(in_frame) & mask);
+    if (unit < p.n_units && threadIdx.x % RT_UNIT == 0u) {
+        p.unit_empty_out[unit] = empty ? 1 : 0;
+        if (empty && pixels) atomicAdd(p.unit_counts_out + 1, pixels);
+    }
+}
+
+// The other units, in ascending order: one workgroup, every thread a contiguous share.
+__global__ __launch_bounds__(1024) void rt_units_compact_kernel(RtParams p)
+{
+    __shared__ uint32_t part[1024];
+    const uint32_t share = (p.n_units + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * share, hi = lo + share < p.n_units ? lo + share : p.n_units;
+    uint32_t n = 0;
+    for (uint32_t u = lo; u < hi; ++u) n += p.unit_empty_out[u] ? 0u : 1u;
+    part[threadIdx.x] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (uint32_t i = 0; i < 1024u; ++i) { const uint32_t v = part[i]; part[i] = sum; sum += v; }
+        p.unit_counts_out[0] = sum;
+    }
+    __syncthreads();
+    uint32_t at = part[threadIdx.x];
+    for (uint32_t u = lo; u < hi; ++u) if (!p.unit_empty_out[u]) p.unit_list_out[at++] = u;
 }
 
 // Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
@@ -2203,6 +2260,14 @@ extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_in
 {
     const unsigned per_block = 256u / RT_UNIT;
     hipLaunchKernelGGL(rt_sum_resolve_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p, frame_index, write_image);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s)
+{
+    const unsigned per_block = 256u / RT_UNIT;
+    hipLaunchKernelGGL(rt_units_classify_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(rt_units_compact_kernel, dim3(1), dim3(1024), 0, s, *p);
     return hipGetLastError();
 }
 

@@ -825,7 +825,7 @@ def test_first_hit_reuse_keeps_every_bit(rt, orc, renderer, parking_renderer, mo
     w, h = 96, 160
     got, want = run_both(rt, orc, renderer, scene, osc, w, h, mode, 8, 3, order=order, reuse=True)
     assert_exact(got, want)
-    assert got["cnt"].primary_hits_reused == 3 * w * h
+    assert got["cnt"].primary_hits_reused + got["cnt"].empty_unit_rays == 3 * w * h and got["cnt"].primary_hits_reused > 0
     # deeper, several Renders per launch: against the same context walking every primary ray
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
     st = renderer.GetSettings()
@@ -838,7 +838,7 @@ def test_first_hit_reuse_keeps_every_bit(rt, orc, renderer, parking_renderer, mo
     st.TraversalOrder, st.ReuseFirstHits = 0, False
     assert np.array_equal(bits(out[True][0]), bits(out[False][0])) and np.array_equal(bits(out[True][1]), bits(out[False][1]))
     assert out[True][2].rays == out[False][2].rays
-    assert out[True][2].primary_hits_reused == 21 * w * h and out[False][2].primary_hits_reused == 0
+    assert out[True][2].primary_hits_reused + out[True][2].empty_unit_rays == 21 * w * h and out[False][2].primary_hits_reused == 0
     # another viewpoint: the hits kept for the first camera must not survive
     cam2 = rt.Camera(70.0, 0.05, 100.0)
     fwd = np.array([-0.2, -0.35, -1.0], np.float32); fwd /= np.linalg.norm(fwd)
@@ -848,6 +848,43 @@ def test_first_hit_reuse_keeps_every_bit(rt, orc, renderer, parking_renderer, mo
     # with parking in this small tree
     got, want = run_both(rt, orc, parking_renderer, scene, osc, w, h, mode, 8, 2, order=order, reuse=True)
     assert_exact(got, want)
+
+
+@pytest.mark.parametrize("order", ORDERS)
+def test_empty_units_are_not_traced(rt, orc, renderer, order):
+    """A scene without spheres: 16-pixel work units none of whose primary rays enters the root box are left out of the trace
+    launch (their Renders add Miss()'s zero) and their TraceRay invocations are counted on the host.  A small mesh in a lot of
+    sky against the oracle -- ids, accumulation, image, ray count -- in single Renders and 5 Renders per launch; the same under a
+    tile split of three contexts; and a camera that looks away from the mesh (nearly every unit empty)."""
+    from raytracer_amd import dist as rtd, scenes
+    centre = np.array([0.3, 0.9, -1.0], np.float32)
+    scene, osc = make_scene(rt, orc, mesh=scenes.cube_sphere(10, center=tuple(centre), radius=0.45), spheres=False)
+    w, h = 200, 150
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 0, 6, 3, order=order)
+    assert_exact(got, want)
+    assert got["cnt"].empty_unit_rays > 0.3 * 3 * w * h and (want["ids"] >= 0).sum() > 500
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings(); st.SceneMode, st.Bounces, st.TraversalOrder = 0, 6, order
+    renderer.ResetFrameIndex(); renderer.Render(scene, cam, frames=3)
+    assert np.array_equal(bits(renderer.read_accum().reshape(-1, 3)), bits(want["acc"]))
+    assert np.array_equal(bits(renderer.GetImage().data.reshape(-1, 4)), bits(want["img"]))
+    acc = np.zeros((h, w, 3), np.float32)
+    for rank in range(3):
+        rr = rt.Renderer(0)
+        s = rr.GetSettings(); s.SceneMode, s.Bounces, s.TraversalOrder = 0, 6, order
+        rr.OnResize(w, h); rr.set_bands(rank, 3)
+        for _ in range(3):
+            rr.Render(scene, cam)
+        rows = rtd.band_rows(h, rank, 3)
+        acc[rows] = rr.read_accum()[rows]
+    assert np.array_equal(bits(acc.reshape(-1, 3)), bits(want["acc"]))
+    st.TraversalOrder = 0
+    away = rt.Camera(70.0, 0.05, 100.0)
+    away.SetPose(np.array([0.0, 1.0, 2.0], np.float32), np.array([0.0, 0.6, 0.8], np.float32))
+    got, want = run_both(rt, orc, renderer, scene, osc, w, h, 0, 6, 2, cam=away, order=order)
+    assert_exact(got, want)
+    # (all but the units of the centre pixel column, whose rays have direction.x == +0 and go to the pre-pass)
+    assert got["cnt"].rays == 2 * w * h and got["cnt"].empty_unit_rays >= 0.9 * 2 * w * h and not want["acc"].any()
 
 
 def test_first_hit_reuse_under_a_tile_split_with_the_filter(rt, orc, renderer):
