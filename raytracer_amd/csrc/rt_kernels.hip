@@ -415,10 +415,10 @@ __device__ __forceinline__ float wave_min(float v)            // wave-uniform re
 // visits a superset of the leaves the one-lane walk visits; a triangle the one-lane walk would have found in a leaf it visits is
 // found here in the same leaf with the same arithmetic, so the closest hit is the same, with ties again resolved to the
 // smallest record index.  `start`: the node cursor of the walk; hit / best_rec: its closest hit so far, in and out (all
-// arguments wave-uniform).
+// arguments wave-uniform).  `cap`: a distance beyond which no hit matters (see tree_body), FLT_MAX = none.
 template <bool ORDERED>
 __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
-                                                 float tol, Hit& hit, uint32_t& best_rec)
+                                                 float tol, float cap, Hit& hit, uint32_t& best_rec)
 {
     bool near_tie = false;
     float t = hit.t, hu = hit.u, hv = hit.v;                // lane-local closest hit; every lane starts from the ray's
@@ -434,7 +434,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
         if (valid) { n0 = nodes[2 * (size_t)j]; n1 = nodes[2 * (size_t)j + 1]; }
         float tNear;
         const bool box = slab_test(n0, n1, O, invD, tNear);
-        const bool descend = valid && box && !(tNear > (ORDERED && RT_NEAR_TIES ? t_prune + (tol + p.tie_rel * t_prune) : t_prune));
+        const bool descend = valid && box && !(tNear > fminf(ORDERED && RT_NEAR_TIES ? t_prune + (tol + p.tie_rel * t_prune) : t_prune, cap));
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
         // ends of the rejected subtrees up to and including this lane's node; a node that is not rejected contributes nothing,
@@ -1659,6 +1659,16 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         }
     };
 
+    // Spheres and mesh together, front-to-back walk: the sphere loop has run when the walk starts, and a triangle farther than the
+    // sphere hit loses to it (Renderer.cpp:292-300: the sphere wins on tS < tT).  The walk therefore never needs to look beyond
+    // tS plus the near-tie distance: a triangle that wins or ties (t <= tS) lies in a leaf whose chain of boxes is entered no
+    // later than t plus half that distance (see RtParams::tie_*), so it is found exactly as without the cap, and anything the
+    // cap hides is beaten by the sphere whatever it is.  No sphere hit: tS = FLT_MAX, no cap.
+    auto sphere_cap = [&]() -> float {
+        if (MODE != RT_MODE_BOTH || !ORDERED) return FLT_MAX;
+        return RT_NEAR_TIES ? tS + (wtol + p.tie_rel * tS) : tS;
+    };
+
     bool parked_hit_ready = false;                          // this lane continues a parked path whose hit the whole-chip kernels found
     uint32_t resume_slot = 0;
     if (p.resume) {
@@ -1852,6 +1862,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         wtol = fmaxf(bx, fmaxf(by, bz)) * p.tie_ulp + p.tie_abs;
                         if (fmaxf(fabsf(s.D.x), fmaxf(fabsf(s.D.y), fabsf(s.D.z))) > 1.001f) wtol = __builtin_inff();
                     }
+                    if (MODE == RT_MODE_BOTH && ORDERED) wprune = sphere_cap();
                     phase = PH_WALK;
                 }
             } else if (begin && phase == PH_BEGIN) {
@@ -1901,7 +1912,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         const uint32_t first = __shfl(wnode, src);
                         const float4* nodes = p.nodes + 2 * ((size_t)__shfl(woct, src) * (size_t)p.n_nodes);
                         const float tol = ORDERED ? __shfl(wtol, src) : 0.0f;
-                        const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, h, best);
+                        const float cap = __shfl(sphere_cap(), src);
+                        const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, cap, h, best);
                         if ((int)lane == src) {
                             th = h; wbest = best; wnode = end;
                             wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + p.tie_rel * h.t) : h.t;
@@ -1947,7 +1959,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                             if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + p.tie_rel * fminf(tt, th.t)) wflag = true;
                             if (tt < th.t || (ORDERED && tt == th.t && wrec < wbest)) {
                                 th.t = tt; th.id = id; th.u = u; th.v = v; wbest = wrec;
-                                wprune = RT_NEAR_TIES ? tt + (wtol + p.tie_rel * tt) : tt;
+                                wprune = fminf(RT_NEAR_TIES ? tt + (wtol + p.tie_rel * tt) : tt, sphere_cap());
                             }
                         }
                         const bool more = (tag & 0x80000000u) == 0u;
