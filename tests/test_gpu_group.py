@@ -88,3 +88,27 @@ def test_group_errors(rt):
     from raytracer_amd import _capi
     with pytest.raises(_capi.RtError):
         rt.GroupRenderer([0, 99], split="tiles")
+
+
+def test_rt_bench_headless_cpp_host():
+    """raytracer_amd/lib/rt_bench (plain C++ over the C ABI): a small mesh scene through its option set -- single Renders, several
+    Renders per launch, kept first hits, the frame copied to the host, two contexts in a tile split.  The same frames are
+    rendered every time, so the device's ray count per frame must be the same in all of them."""
+    import json, os, subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "raytracer_amd", "lib", "rt_bench")
+    assert os.path.exists(exe), "rt_bench is built by raytracer_amd/csrc/Makefile"
+    base = [exe, "--config", "3", "--width", "320", "--height", "200", "--grid", "150", "--frames", "8", "--warmup", "1"]
+    runs = {"single": [], "x4": ["--frames-per-launch", "4"], "reuse": ["--frames-per-launch", "4", "--reuse-first-hits", "1"],
+            "d2h": ["--d2h", "2"], "tiles": ["--devices", "0,0", "--split", "tiles", "--frames-per-launch", "2"]}
+    out = {}
+    for name, extra in runs.items():
+        p = subprocess.run(base + extra, capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, (name, p.stderr[-400:])
+        out[name] = json.loads(p.stdout.strip().splitlines()[-1])
+        assert out[name]["frames"] == 8 and out[name]["ms_per_frame"] > 0 and out[name]["mrays_per_s"] > 0
+    rays = {name: o["rays_per_frame"] for name, o in out.items()}
+    assert len(set(rays.values())) == 1 and rays["single"] >= 320 * 200, rays
+    assert out["reuse"]["primary_hits_reused_per_frame"] > 0 and out["single"]["primary_hits_reused_per_frame"] == 0
+    assert out["reuse"]["primary_hits_reused_per_frame"] + out["reuse"]["empty_unit_rays_per_frame"] == 320 * 200
+    assert out["tiles"]["devices"] == 2 and out["tiles"]["split"] == "tiles"

@@ -23,14 +23,23 @@ for cfg in (1, 2, 3, 4, 5):
         if os.path.exists(d + "_bench.json") and os.path.getsize(d + "_bench.json"):
             shutil.copy(d + "_bench.json", os.path.join(root, "profiles", name + "_bench.json"))
         s = json.load(open(summ))
+        # launches of the timed kind in the profiled command (timed + warm-up); the trace kernel of a scene that parks rays is
+        # also launched, small, to finish the parked paths: the per-launch means are scaled to the launches that draw units
+        n_main = None
+        if os.path.exists(d + "_bench.json") and os.path.getsize(d + "_bench.json"):
+            b = json.loads(open(d + "_bench.json").read())
+            n_main = b["roofline"]["launches"] + (b["warmup"] if kind == "single" else 0)
         for k, cs in s["counters"].items():
             # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
             timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
             if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
                 key = "config%d" % cfg if kind == "single" else "config%d_x16" % cfg
+                calls = cs["FETCH_SIZE"]["launches"]
+                scale = calls / n_main if n_main and calls > n_main else 1.0
                 traffic[key] = {
                     "kernel": k, "fetch_size_KiB": cs["FETCH_SIZE"]["mean"], "write_size_KiB": cs["WRITE_SIZE"]["mean"],
-                    "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0,
+                    "kernel_launches_in_pass": calls, "of_which_draw_units": n_main if n_main else calls,
+                    "hbm_bytes_per_launch": (2.0 * cs["FETCH_SIZE"]["mean"] + cs["WRITE_SIZE"]["mean"]) * 1024.0 * scale,
                     "launch": "one Render" if kind == "single" else "16 Renders",
                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh %d %s, round tag %s" % (cfg, kind, tag)}
 json.dump(traffic, open(traffic_path, "w"), indent=1)
