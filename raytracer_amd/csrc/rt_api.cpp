@@ -742,7 +742,9 @@ int rt_set_camera(rt_ctx* c, const float pos[3], const float inv_proj[16], const
     if (!c || !pos || !inv_proj || !inv_view) return RT_E_ARG;
     // directions are regenerated only when the matrices change (Camera.cpp:96-100,113-114)
     if (!c->have_camera || memcmp(c->inv_proj, inv_proj, 64) != 0 || memcmp(c->inv_view, inv_view, 64) != 0) c->dirs_dirty = true;
-    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;     // the column rays start at the camera
+    if (!c->have_camera || memcmp(c->cam_pos, pos, 12) != 0) {          // the primary rays start at the camera
+        c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;
+    }
     memcpy(c->cam_pos, pos, 12); memcpy(c->inv_proj, inv_proj, 64); memcpy(c->inv_view, inv_view, 64);
     c->have_camera = true;
     return RT_OK;
