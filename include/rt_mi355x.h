@@ -105,9 +105,11 @@ typedef struct {
    `rays`, whose hit came from the kept first hits (rt_settings.reuse_first_hits) instead of a walk.  empty_unit_rays (always
    maintained): primary rays, part of `rays`, of 16-pixel work units none of whose primary rays enters the tree's root box -- in a
    scene without spheres those paths end in Miss() with a colour of zero (Renderer.cpp:160-165) and are not traced at all (found
-   once per camera, directions, bands and tree; the counting mode of rt_set_stats traces them like any other). */
+   once per camera, directions, bands and tree; the counting mode of rt_set_stats traces them like any other).  view_setups:
+   how often that per-view data (the list of units to trace, the kept first hits) was built since the last reset -- it should
+   stay put while the same camera and scene are re-sent frame after frame. */
 typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties, primary_hits_reused,
-                 empty_unit_rays; } rt_counters;
+                 empty_unit_rays, view_setups; } rt_counters;
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh

@@ -94,6 +94,7 @@ struct rt_ctx {
     bool units_valid = false;            // they belong to the current camera, directions, bands and tree
     uint32_t n_list = 0, empty_pixels = 0;
     unsigned long long host_rays = 0;    // primary rays of empty units: TraceRay invocations that needed no kernel
+    unsigned long long view_setups = 0;  // times the unit list or the first hits were built
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
@@ -822,7 +823,7 @@ int ensure_units(rt_ctx* c, RtParams& p)
         HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr, sizeof counts, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_list = counts[0]; c->empty_pixels = counts[1];
-        c->units_valid = true;
+        c->units_valid = true; c->view_setups++;
     }
     p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr;
     return RT_OK;
@@ -960,7 +961,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
         unsigned grid1;
         if (int rc = trace_grid(c, mode, false, ordered, n_traced_units, grid1)) return rc;
         if (int rc = trace_and_finish_parked(c, q, mode, ordered, grid1, nullptr)) return rc;
-        c->first_hits_valid = true;
+        c->first_hits_valid = true; c->view_setups++;
     }
     if (reuse) { p.first_hits = c->d_first_hits.ptr; p.first_hit_mode = 2u; }
     // sphere frames resolve inside the trace kernel; the 3x3 filter needs the neighbours' sums and keeps the separate pass
@@ -1172,7 +1173,7 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
     out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2]; out->primary_hits_reused = cs[3];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
-    out->rays += c->host_rays; out->empty_unit_rays = c->host_rays;
+    out->rays += c->host_rays; out->empty_unit_rays = c->host_rays; out->view_setups = c->view_setups;
     return RT_OK;
 }
 
@@ -1183,7 +1184,7 @@ int rt_reset_counters(rt_ctx* c)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 4 * sizeof(unsigned long long), c->stream));
-    c->host_rays = 0;
+    c->host_rays = 0; c->view_setups = 0;
     return RT_OK;
 }
 

@@ -686,10 +686,16 @@ def test_configs4_and_5_ten_million_triangles_4k(rt, orc, renderer):
             acc_differ = (bits(full[REF_ORDER][1]) != bits(full[F2B_ORDER][1])).any(axis=-1).sum()
             assert acc_differ == 0, "%d pixels of accumulated radiance differ between the walk orders" % acc_differ
             print("mode %d: %d primary ids, %d radiance pixels differ between walk orders (of %d)" % (mode, len(differ), acc_differ, w * h))
+            # kept first hits at full size (auto order = front to back here): the same ids and sums again
+            st.TraversalOrder, st.ReuseFirstHits = 0, True
+            renderer.ResetFrameIndex(); renderer.Render(scene, cam, frames=2)
+            st.ReuseFirstHits = False
+            assert np.array_equal(renderer.read_primary_ids(), full[F2B_ORDER][0]), "mode %d: primary ids with kept first hits" % mode
+            assert np.array_equal(bits(renderer.read_accum()), bits(full[F2B_ORDER][1])), "mode %d: accumulation with kept first hits" % mode
             hit = full[F2B_ORDER][0] >= 0
             assert hit.mean() > 0.15 and (full[F2B_ORDER][0] >= 0x40000000).sum() > 200000   # the mesh is seen
     finally:
-        st.TraversalOrder = 0; renderer.download = True
+        st.TraversalOrder = 0; st.ReuseFirstHits = False; renderer.download = True
 
 
 # ---- plumbing for the multi-GPU path, on one GPU ------------------------------------------------------------------------------
@@ -826,6 +832,8 @@ def test_first_hit_reuse_keeps_every_bit(rt, orc, renderer, parking_renderer, mo
     got, want = run_both(rt, orc, renderer, scene, osc, w, h, mode, 8, 3, order=order, reuse=True)
     assert_exact(got, want)
     assert got["cnt"].primary_hits_reused + got["cnt"].empty_unit_rays == 3 * w * h and got["cnt"].primary_hits_reused > 0
+    # camera and scene were re-sent before every Render: the per-view data was built once (unit list in mesh mode, first hits)
+    assert got["cnt"].view_setups == (2 if mode == 0 else 1)
     # deeper, several Renders per launch: against the same context walking every primary ray
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
     st = renderer.GetSettings()
