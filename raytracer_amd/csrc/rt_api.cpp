@@ -23,7 +23,7 @@ extern "C" hipError_t rt_trace_occupancy(int mode, int stats, int ordered, int* 
 extern "C" unsigned rt_trace_block(int mode);
 extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
-extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int cached, hipStream_t s);
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s);
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
@@ -85,7 +85,7 @@ struct rt_ctx {
     // accumulation was last restarted, i.e. whether the filter may read them
     bool halo_complete = true;
     bool halo_in_columns = false;        // the column-ray numbering in d_dirs.w includes the halo rows
-    bool column_cache = false;           // the pre-pass queue on the device belongs to the current camera, directions, bands and tree
+    bool column_cache = false;           // the column rays' hits on the device belong to the current camera, directions, bands and tree
     DevBuf<float4> d_first_hits;         // rt_settings.reuse_first_hits: the primary ray's mesh hit per pixel ...
     bool first_hits_valid = false;       // ... and whether it belongs to the current camera, directions, bands, tree and walk order
     // mesh-only scenes: the work units in which a primary ray can hit anything (the others are not traced, see RtParams::unit_list)
@@ -944,17 +944,18 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // events: [pre, start) = what precedes the trace kernel on mesh scenes (the column pre-pass when the camera has direction.x == +0
     // pixels, the launch that stores first hits), [start, stop) = the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
-    const bool prepass = tree && c->n_columns && (!reuse || store_first);     // (stored hits answer the column rays too)
+    const bool columns = tree && c->n_columns && (!reuse || store_first);     // (stored hits answer the column rays too)
+    // Which triangle a column ray hits depends on the camera, the directions, the bands and the tree only: the pre-pass runs when
+    // one of those changed and its result (the best hit per column ray) is kept.  The counting kernels always run it: their
+    // counters describe what the reference's walk costs for these rays.
+    const bool prepass = columns && (!c->column_cache || c->stats);
     c->ev_has_pre[ev] = prepass || store_first;
     if (c->ev_has_pre[ev]) HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
     if (prepass) {
-        // Which leaf records the column rays can hit depends on the camera, the directions and the tree only: found once and kept
-        // (the queue of undecided (record, 16 rays) pairs); every launch repeats the triangle tests on that queue.  The counting
-        // kernels always run the whole pre-pass: their counters describe what the reference's walk costs for these rays.
-        const bool cached = c->column_cache && !c->stats;
-        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, cached ? 1 : 0, c->stream));
+        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
         c->column_cache = true;
-    } else p.column_best = nullptr;
+    }
+    if (!columns) p.column_best = nullptr;
     if (store_first) {
         RtParams q = p;
         q.n_frames = 1; q.first_hits = c->d_first_hits.ptr; q.first_hit_mode = 1u; q.primary_ids = nullptr;

@@ -2230,17 +2230,15 @@ static void launch_reach(const RtParams& p, int stats, hipStream_t s)
     hipLaunchKernelGGL(rt_column_reach_mark_kernel, dim3(node_blocks), dim3(256), 0, s, p, stats);
 }
 
-// `cached`: the queue of undecided (record, 16 rays) pairs on the device still describes this camera, these directions and this
-// tree (it does not depend on anything else), so only the triangle tests on it are repeated.
-extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, int cached, hipStream_t s)
+// The hits of the column rays (column_best, column_flags).  They depend on the camera, the directions, the bands and the tree
+// only: the caller keeps them until one of those changes.
+extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s)
 {
     RtParams q = *p; q.ray_slot = -1;
     hipLaunchKernelGGL(rt_column_reset_kernel, dim3((q.column_cap + 255u) / 256u), dim3(256), 0, s, q);
     if (q.n_refs == 0u) return hipGetLastError();                              // a tree without a triangle: every column ray misses
-    if (!cached) {
-        launch_reach(q, stats, s);
-        hipLaunchKernelGGL(rt_column_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
-    }
+    launch_reach(q, stats, s);
+    hipLaunchKernelGGL(rt_column_filter_kernel, dim3((q.n_refs + 255u) / 256u), dim3(256), 0, s, q, stats);
     hipLaunchKernelGGL(rt_column_exact_kernel, dim3(2048), dim3(256), 0, s, q);
     return hipGetLastError();
 }
