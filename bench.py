@@ -204,9 +204,11 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
     own_tris = per_launch(c2.tris_tested - c2.prepass_tris)
     # (the counting pass traces every ray; primary rays of empty work units are not traced by the timed kernel: their one node
     # and their hit record are taken out again)
+    # ... and so are the first steps of primary walks that start at their unit's entry node)
     skipped = cnt.empty_unit_rays / launches
-    bytes_ = ((own_nodes - skipped) * BYTES_PER_NODE + own_tris * BYTES_PER_TRI + (rays_per_launch - skipped) * BYTES_PER_HIT
-              + px * BYTES_PER_PIXEL_FRAME)
+    spared_nodes, spared_tris = cnt.entry_nodes_spared / launches, cnt.entry_tris_spared / launches
+    bytes_ = ((own_nodes - skipped - spared_nodes) * BYTES_PER_NODE + (own_tris - spared_tris) * BYTES_PER_TRI
+              + (rays_per_launch - skipped) * BYTES_PER_HIT + px * BYTES_PER_PIXEL_FRAME)
     achieved = bytes_ / avg_kernel_s / 1e9
     small = cfg["mesh"][1] < 1000
     return {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
@@ -217,14 +219,16 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
             "kernel": "rt_trace_kernel<%s, %s>" % ("mesh" if cfg["mode"] == 0 else "spheres+mesh", order_used),
             "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
             "prepass_avg_ms": kt.prepass_total_ms / launches,
-            "nodes_per_ray": own_nodes / max(rays_per_launch, 1), "tris_per_ray": own_tris / max(rays_per_launch, 1),
+            "nodes_per_ray": (own_nodes - skipped - spared_nodes) / max(rays_per_launch, 1),
+            "tris_per_ray": (own_tris - spared_tris) / max(rays_per_launch, 1),
             "column_rays_reference_equivalent": {"nodes_per_frame": per_frame(c2.prepass_nodes), "tris_per_frame": per_frame(c2.prepass_tris)},
-            "rays_per_launch": rays_per_launch, "rays_not_traced_per_launch": skipped, "traversal": order_used, "reference_order_counts": ref_counts,
+            "rays_per_launch": rays_per_launch, "rays_not_traced_per_launch": skipped,
+            "primary_walk_steps_spared_per_launch": {"nodes": spared_nodes, "tris": spared_tris}, "traversal": order_used, "reference_order_counts": ref_counts,
             "grazing_ties": order_ties,
             "near_tie_rewalks_per_frame": per_frame(cnt.near_ties),
             "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per traced ray for the hit's "
                     "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
-                    "that was timed; primary rays of 16-pixel units that miss the root box altogether are not traced and not priced; `frac` prices them against the HBM peak as the contract asks, `frac_hbm_moved` is what the PMC "
+                    "that was timed; primary rays of 16-pixel units that miss the root box altogether are not traced and not priced, nor are the first steps of primary walks that start at their unit's common entry node; `frac` prices them against the HBM peak as the contract asks, `frac_hbm_moved` is what the PMC "
                     "counters saw reach HBM; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "
                     + ("nodes (8 x 3.6 MB) + leaf records (17 MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
                        else "nodes (8 x 0.5 GB) + leaf records (2.4 GB) are HBM-resident: random 32-48 B reads")}

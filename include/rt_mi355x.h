@@ -107,9 +107,12 @@ typedef struct {
    scene without spheres those paths end in Miss() with a colour of zero (Renderer.cpp:160-165) and are not traced at all (found
    once per camera, directions, bands and tree; the counting mode of rt_set_stats traces them like any other).  view_setups:
    how often that per-view data (the list of units to trace, the kept first hits) was built since the last reset -- it should
-   stay put while the same camera and scene are re-sent frame after frame. */
+   stay put while the same camera and scene are re-sent frame after frame.  entry_nodes_spared / entry_tris_spared: node steps
+   and triangle tests of primary walks that were not made because the sixteen primary rays of a work unit share the first
+   decisions of their walks (same origin, neighbouring directions) and start at the node where they part -- up to there
+   none of them has hit anything (mesh-only scenes; found with the unit list; not in counting mode). */
 typedef struct { uint64_t rays, nodes_visited, tris_tested, sphere_tests, prepass_nodes, prepass_tris, near_ties, primary_hits_reused,
-                 empty_unit_rays, view_setups; } rt_counters;
+                 empty_unit_rays, view_setups, entry_nodes_spared, entry_tris_spared; } rt_counters;
 
 /* Device time measured with HIP events on the stream the kernels were launched on: total_ms / last_ms over the
    trace kernel (the dominant kernel) alone, prepass_total_ms over the pre-pass kernels that precede it on mesh

@@ -45,7 +45,7 @@ class RtCounters(C.Structure):
     _fields_ = [("rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("prepass_nodes", C.c_uint64), ("prepass_tris", C.c_uint64), ("near_ties", C.c_uint64),
                 ("primary_hits_reused", C.c_uint64), ("empty_unit_rays", C.c_uint64),
-                ("view_setups", C.c_uint64)]
+                ("view_setups", C.c_uint64), ("entry_nodes_spared", C.c_uint64), ("entry_tris_spared", C.c_uint64)]
 
 
 class RtKernelTime(C.Structure):

@@ -25,6 +25,7 @@ extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s);
+extern "C" hipError_t rt_launch_units_entry(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s);
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
@@ -90,9 +91,10 @@ struct rt_ctx {
     bool first_hits_valid = false;       // ... and whether it belongs to the current camera, directions, bands, tree and walk order
     // mesh-only scenes: the work units in which a primary ray can hit anything (the others are not traced, see RtParams::unit_list)
     DevBuf<unsigned char> d_unit_empty;
-    DevBuf<uint32_t> d_unit_list, d_unit_counts;
+    DevBuf<uint32_t> d_unit_list, d_unit_counts, d_unit_entry;
     bool units_valid = false;            // they belong to the current camera, directions, bands and tree
-    uint32_t n_list = 0, empty_pixels = 0;
+    uint32_t n_list = 0, empty_pixels = 0, entry_nodes = 0, entry_tris = 0;
+    unsigned long long host_entry_nodes = 0, host_entry_tris = 0;    // steps the entry points spared the primary walks
     unsigned long long host_rays = 0;    // primary rays of empty units: TraceRay invocations that needed no kernel
     unsigned long long view_setups = 0;  // times the unit list or the first hits were built
     DevBuf<uint32_t> d_sphere_mat, d_work_heads;
@@ -364,7 +366,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
     c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release();
-    c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release();
+    c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release(); c->d_unit_entry.release();
     for (int i = 0; i < rt_ctx::UP_RING; ++i) {
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
         if (c->up_buf[i]) (void)hipHostFree(c->up_buf[i]);
@@ -427,7 +429,7 @@ int rt_set_settings(rt_ctx* c, const rt_settings* s)
     if (!c || !s) return RT_E_ARG;
     if (s->scene_mode < 0 || s->scene_mode > 2) return fail(c, RT_E_ARG, "scene_mode %d", s->scene_mode);
     if (s->traversal < RT_ORDER_AUTO || s->traversal > RT_ORDER_FRONT_TO_BACK) return fail(c, RT_E_ARG, "traversal %d", s->traversal);
-    if (s->scene_mode != c->settings.scene_mode || s->traversal != c->settings.traversal) c->first_hits_valid = false;
+    if (s->scene_mode != c->settings.scene_mode || s->traversal != c->settings.traversal) { c->first_hits_valid = false; c->units_valid = false; }
     c->settings = *s;
     return RT_OK;
 }
@@ -807,25 +809,36 @@ int ensure_columns(rt_ctx* c, RtParams& p)
 
 // Mesh-only scenes: which work units hold a primary ray that enters the root box (RtParams::unit_list); the two counts are read
 // back once per change, like the column count.
-int ensure_units(rt_ctx* c, RtParams& p)
+int ensure_units(rt_ctx* c, RtParams& p, bool ordered)
 {
     if (!c->units_valid) {
+        const size_t pixels = (size_t)c->width * c->height;
+        if (c->d_unit_entry.count != pixels) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, c->d_unit_entry.resize(pixels));
+        }
         if (c->d_unit_empty.count < p.n_units) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, c->d_unit_empty.resize(p.n_units));
             HIP_TRY(c, c->d_unit_list.resize(p.n_units));
         }
-        if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(2));
+        if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(4));
         p.unit_empty_out = c->d_unit_empty.ptr; p.unit_list_out = c->d_unit_list.ptr; p.unit_counts_out = c->d_unit_counts.ptr;
-        HIP_TRY(c, hipMemsetAsync(c->d_unit_counts.ptr, 0, 2 * sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_unit_counts.ptr, 0, 4 * sizeof(uint32_t), c->stream));
         HIP_TRY(c, rt_launch_units_classify(&p, c->stream));
         uint32_t counts[2] = {0, 0};
         HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr, sizeof counts, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_list = counts[0]; c->empty_pixels = counts[1];
+        // where the primary walks of the listed units may start, for the walk order in use
+        p.n_list = c->n_list; p.unit_entry_out = c->d_unit_entry.ptr; p.entry_ordered = ordered ? 1u : 0u;
+        HIP_TRY(c, rt_launch_units_entry(&p, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr + 2, sizeof counts, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->entry_nodes = counts[0]; c->entry_tris = counts[1];
         c->units_valid = true; c->view_setups++;
     }
-    p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr;
+    p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr; p.unit_entry = c->d_unit_entry.ptr;
     return RT_OK;
 }
 
@@ -926,7 +939,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     const bool ordered = tree && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     // Units without a primary ray into the root box are not traced (a scene without spheres; the counting kernels trace all)
     const bool skip_empty = mode == RT_SCENE_MESH && c->settings.bounces != 0u && !c->stats;
-    if (skip_empty) { if (int rc = ensure_units(c, p)) return rc; }
+    if (skip_empty) { if (int rc = ensure_units(c, p, ordered)) return rc; }
     const uint32_t n_traced_units = skip_empty ? p.n_list : p.n_units;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, ordered, n_traced_units * (tree ? n : 1u), grid)) return rc;
@@ -973,7 +986,10 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, c->ev_stop[ev])) return rc;
     c->ev_frames[ev] = n;
     c->ev_head++;
-    if (skip_empty) c->host_rays += (unsigned long long)c->empty_pixels * n;
+    if (skip_empty) {
+        c->host_rays += (unsigned long long)c->empty_pixels * n;
+        if (!reuse) { c->host_entry_nodes += (unsigned long long)c->entry_nodes * n; c->host_entry_tris += (unsigned long long)c->entry_tris * n; }
+    }
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
     if (tree) HIP_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
@@ -1175,6 +1191,7 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2]; out->primary_hits_reused = cs[3];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
     out->rays += c->host_rays; out->empty_unit_rays = c->host_rays; out->view_setups = c->view_setups;
+    out->entry_nodes_spared = c->host_entry_nodes; out->entry_tris_spared = c->host_entry_tris;
     return RT_OK;
 }
 
@@ -1185,7 +1202,7 @@ int rt_reset_counters(rt_ctx* c)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 4 * sizeof(unsigned long long), c->stream));
-    c->host_rays = 0; c->view_setups = 0;
+    c->host_rays = 0; c->view_setups = 0; c->host_entry_nodes = 0; c->host_entry_tris = 0;
     return RT_OK;
 }
 

@@ -139,12 +139,19 @@ struct RtParams {
     // Mesh-only scenes, optional: work units none of whose primary rays enters the root box ("empty": their paths end in
     // Miss() with a colour of 0 + 1 * 0, Renderer.cpp:160-165).  Found when camera, directions, bands or tree change; the trace
     // kernel then draws its tickets over unit_list (the n_list other units, ascending) and the resolve pass takes a radiance of
-    // zero for the units marked in unit_empty.  unit_out: where the classification writes (unit_empty, list, {n_list, pixels
-    // of empty units}).
+    // zero for the units marked in unit_empty.  unit_*_out: where the classification writes (unit_empty, list, counts = {n_list,
+    // pixels of empty units, node steps and triangle tests that unit_entry spares the primary walks of one Render}).
     const uint32_t* unit_list;
     uint32_t n_list;
     const unsigned char* unit_empty;
     unsigned char* unit_empty_out; uint32_t* unit_list_out; uint32_t* unit_counts_out;
+    // ... and where the walk of a primary ray may start.  The sixteen primary rays of a unit make the same decisions at the first
+    // nodes of their walk (same origin, neighbouring directions): unit_entry[pixel] is the first node at which they do not --
+    // a box some enter and some miss, or a leaf in which one of them hits a triangle.  Up to there no ray of the unit has hit
+    // anything, so a walk that starts at that node with no hit is in exactly the state the walk from the root would be in.
+    // Found with the unit list, for the walk order in `entry_ordered`; null = every walk starts at the root.
+    const uint32_t* unit_entry;
+    uint32_t* unit_entry_out; uint32_t entry_ordered;
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop

@@ -1849,6 +1849,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     woct = 0;
                     if (ORDERED) woct = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
+                    if (MODE == RT_MODE_MESH && !STATS && s.bounce == 1u && p.unit_entry) wnode = p.unit_entry[pixel];   // (see RtParams::unit_entry)
                     wprune = FLT_MAX; wflag = false;
                     if (ORDERED && RT_NEAR_TIES) {
                         // The part of the near-tie distance that does not grow with t (see RtParams::tie_*): the rounding of a box's
@@ -2099,6 +2100,70 @@ __global__ __launch_bounds__(256) void rt_units_classify_kernel(RtParams p)
     }
 }
 
+// Where the walks of a listed unit's primary rays may start (RtParams::unit_entry): sixteen lanes per unit walk in step, with the
+// decisions of tree_body's node_step / rec_step for a ray that has no hit yet, until two of them decide differently or one
+// of them hits a triangle.  Rays with direction.x == 0 do not walk (pre-pass) and have no say.
+__global__ __launch_bounds__(256) void rt_units_entry_kernel(RtParams p)
+{
+    const uint32_t li = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    const bool listed = li < p.n_list;
+    const uint32_t unit = listed ? p.unit_list_out[li] : 0u;
+    uint32_t pixel = 0;
+    const bool in_frame = listed && unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel);
+    const uint32_t group = (threadIdx.x & 63u) / RT_UNIT;
+    const unsigned long long mask = 0xFFFFull << (RT_UNIT * group);
+    F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]), D = f3(1.0f, 1.0f, 1.0f);
+    if (in_frame) { const float4 d = p.dirs[pixel]; D = f3(d.x, d.y, d.z); }
+    const bool live = in_frame && D.x != 0.0f;
+    const F3 invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+    uint32_t oct = 0;
+    if (p.entry_ordered) oct = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
+    // one node array for the whole unit, or no common start
+    const unsigned long long lives = __ballot(live) & mask;
+    const uint32_t oct0 = lives ? (uint32_t)__shfl((int)oct, __ffsll((long long)lives) - 1) : 0u;
+    bool done = lives == 0ull || (__ballot(live && oct != oct0) & mask) != 0ull;
+    const float4* nodes = p.nodes + 2 * ((size_t)oct0 * (size_t)p.n_nodes);
+    const uint32_t end = p.n_nodes;
+    uint32_t cursor = 0, n_nodes = 0, n_tris = 0;           // steps the walks of this unit's live rays are spared
+    while (__ballot(!done) != 0ull) {
+        if (!done) {
+            if (cursor >= end) done = true;                 // every ray of the unit misses everything
+            else {
+                const float4 n0 = nodes[2 * (size_t)cursor], n1 = nodes[2 * (size_t)cursor + 1];
+                float tNear;
+                const bool box = slab_test(n0, n1, O, invD, tNear);
+                const bool descend = box && !(tNear > FLT_MAX);
+                const unsigned long long yes = __ballot(live && descend) & mask, no = __ballot(live && !descend) & mask;
+                const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+                if (yes != 0ull && no != 0ull) done = true;
+                else if (no != 0ull || (leaf_first < 0 && leaf_first != RT_LEAF_INTERIOR)) { cursor = __float_as_uint(n0.w); n_nodes++; }   // all miss the box, or a leaf without records
+                else if (leaf_first == RT_LEAF_INTERIOR) { cursor = cursor + 1u; n_nodes++; }
+                else {
+                    bool hit = false;
+                    uint32_t tested = 0;
+                    for (uint32_t rec = (uint32_t)leaf_first;; ++rec) {
+                        const float4* r = p.leafrecs + 3 * (size_t)rec;
+                        const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        float tt, u, v;
+                        if (tri_test(r0, r1, r2, O, D, tt, u, v) && live) hit = true;
+                        tested++;
+                        if (__float_as_uint(r2.y) & 0x80000000u) break;
+                    }
+                    if ((__ballot(hit) & mask) != 0ull) done = true;
+                    else { cursor = __float_as_uint(n0.w); n_nodes++; n_tris += tested; }
+                }
+            }
+        }
+    }
+    if (in_frame) p.unit_entry_out[pixel] = cursor;
+    if (!live) { n_nodes = 0; n_tris = 0; }
+    for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
+    if ((threadIdx.x & 63u) == 0u) {
+        atomicAdd(p.unit_counts_out + 2, n_nodes);
+        atomicAdd(p.unit_counts_out + 3, n_tris);
+    }
+}
+
 // The other units, in ascending order: one workgroup, every thread a contiguous share.
 __global__ __launch_bounds__(1024) void rt_units_compact_kernel(RtParams p)
 {
@@ -2278,6 +2343,13 @@ extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s)
     const unsigned per_block = 256u / RT_UNIT;
     hipLaunchKernelGGL(rt_units_classify_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p);
     hipLaunchKernelGGL(rt_units_compact_kernel, dim3(1), dim3(1024), 0, s, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_launch_units_entry(const RtParams* p, hipStream_t s)
+{
+    const unsigned per_block = 256u / RT_UNIT;
+    if (p->n_list) hipLaunchKernelGGL(rt_units_entry_kernel, dim3((p->n_list + per_block - 1u) / per_block), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 
