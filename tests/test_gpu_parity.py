@@ -242,6 +242,10 @@ def test_mesh_orders_agree_from_other_viewpoints(rt, orc, renderer, side):
     for order in (REF_ORDER, F2B_ORDER):
         got, want = run_both(rt, orc, renderer, scene, osc, 144, 96, 0, 6, 2, stats=True, cam=cam, order=order)
         assert_mesh(got, want, order)
+        # ... and the kernels that are timed: units that are not traced, primary walks from their unit's entry node
+        got, want = run_both(rt, orc, renderer, scene, osc, 144, 96, 0, 6, 2, stats=False, cam=cam, order=order)
+        assert_exact(got, want)
+        assert got["cnt"].entry_nodes_spared > 0
     assert (want["ids"] >= 0).sum() > 1000
 
 
@@ -795,7 +799,8 @@ def parking_renderer(rt, monkeypatch):
 def test_zero_direction_rays_parked_and_resumed(rt, orc, parking_renderer, mode, order):
     """Same planted zero components as the test below, through the parking path: more such rays than parking slots, so some
     are parked and resumed and the rest are walked in the kernel, in one frame."""
-    test_zero_direction_components_all_patterns(rt, orc, parking_renderer, mode, order)
+    test_zero_direction_components_all_patterns(rt, orc, parking_renderer, mode, order, False)
+    test_zero_direction_components_all_patterns(rt, orc, parking_renderer, mode, order, True)
 
 
 @pytest.mark.parametrize("mirror_walls", [False, True], ids=["one-round", "a-round-per-bounce"])
@@ -915,12 +920,15 @@ def test_first_hit_reuse_under_a_tile_split_with_the_filter(rt, orc, renderer):
     assert np.array_equal(bits(img.reshape(-1, 4)), bits(want["img"]))
 
 
+@pytest.mark.parametrize("counting", [True, False], ids=["counting-kernels", "timed-kernels"])
 @pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("mode", [0, 2])
-def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
+def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order, counting):
     """Host-supplied directions with +0 / -0 planted in x, y, z (alone and combined) on scattered pixels, next to the default
     camera's own +0 column: the pre-pass (x == +0 primaries), the wave-cooperative walk (x == -0, and any bounce) and the
-    ordinary walk (zeros in y / z only) must all reproduce the reference's visited sets and hits."""
+    ordinary walk (zeros in y / z only) must all reproduce the reference's visited sets and hits.  With the counting kernels
+    (every unit traced from the root, node and triangle counters compared) and with the kernels that are timed (units that are
+    not traced, primary walks that start at their unit's entry node)."""
     from raytracer_amd import scenes
     w, h = 128, 80
     scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(28))
@@ -943,7 +951,7 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
     st = renderer.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, 5, True, False, True, 1337
     st.TraversalOrder = order
-    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(True); renderer.reset_counters()
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(counting); renderer.reset_counters()
     renderer.upload(scene, cam)
     renderer.set_ray_dirs(dirs)
     try:
@@ -956,6 +964,7 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order):
         got = dict(ids=renderer.read_primary_ids().ravel(), acc=renderer.read_accum().reshape(-1, 3),
                    img=renderer.GetImage().data.reshape(-1, 4), cnt=renderer.read_counters())
         # NaN never equals NaN bitwise-safe compare is what bits() does; a ray going nowhere yields NaN radiance in both
-        assert_mesh(got, dict(ids=ids, acc=acc, img=img, cnt=cnt), order)
+        if counting: assert_mesh(got, dict(ids=ids, acc=acc, img=img, cnt=cnt), order)
+        else: assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=cnt))
     finally:
         renderer.set_ray_dirs(None); renderer.set_stats(False); st.TraversalOrder = 0
