@@ -53,8 +53,39 @@ __device__ __forceinline__ float sqrt_rn(float x)
     return r;
 }
 
+// 1.0f / sqrt_rn(x): both operations correctly rounded, bit for bit what the two separate routines give.  For x in
+// [2^-96, FLT_MAX] the root lies in [2^-48, 2^64], where the compiler's own expansion of an fp32 division neither rescales its
+// operands nor needs its final special-case pass: what is left of it for a numerator of 1 is the hardware reciprocal and six
+// FMAs (its first quotient 1 * r is r itself).  Any other x takes the general routines behind the same wave-wide test.
+#ifndef RT_FAST_RSQRT
+#define RT_FAST_RSQRT 1
+#endif
+__device__ __forceinline__ float rsqrt_rn(float x)
+{
+#if RT_FAST_RSQRT
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float below = __uint_as_float(__float_as_uint(s) - 1u), above = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+    float d = (0.0f >= r_below) ? below : s;
+    d = (0.0f < r_above) ? above : d;
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+    const bool general = !(x >= 0x1p-96f && x <= FLT_MAX);
+    if (__ballot(general) != 0ull) {
+        float y = x;
+        asm volatile("" : "+v"(y));
+        if (general) q = 1.0f / sqrtf(y);
+    }
+    return q;
+#else
+    return 1.0f / sqrt_rn(x);
+#endif
+}
+
 // glm::normalize = v * (1 / sqrt(dot(v, v))) (func_geometric.inl:82-90, func_exponential.inl:134-139)
-__device__ __forceinline__ F3 normalize3(F3 v) { return v * (1.0f / sqrt_rn(dot3(v, v))); }
+__device__ __forceinline__ F3 normalize3(F3 v) { return v * rsqrt_rn(dot3(v, v)); }
 // glm::reflect = I - N * dot(N, I) * 2 (func_geometric.inl:104-110)
 __device__ __forceinline__ F3 reflect3(F3 I, F3 N) { return I - (N * dot3(N, I)) * 2.0f; }
 // glm::mix = x * (1 - a) + y * a (func_common.inl:104-112)
@@ -263,6 +294,24 @@ __device__ __forceinline__ void trace_spheres_from(const RtParams& p, F3 O, F3 D
         if (i + 2u < n) even = INLINE ? p.sph_inline[i + 2u] : p.spheres[i + 2u];
         sphere_test(odd, (int)i + 1, O, D, dbl_a, four_a, best);
     }
+    if (best.index >= 0) {
+        const float t = best.num / dbl_a;
+        if (t > 0.0f && t < closest) { closest = t; index = best.index; }
+    }
+}
+
+#ifndef RT_SPHERE_LDS_LOOP
+#define RT_SPHERE_LDS_LOOP 1
+#endif
+// The same loop over the workgroup's copy of the sphere table in LDS: every lane reads the same address (one broadcast read
+// straight into vector registers, no scalar load, no address arithmetic on the scalar unit, no copies from scalar registers).
+__device__ __forceinline__ void trace_spheres_lds(const float4* spheres, uint32_t n, F3 O, F3 D, float& closest, int& index)
+{
+    float a = dot3(D, D);
+    float dbl_a = 2.0f * a;
+    float four_a = 4.0f * a;
+    SphereBest best; best.num = __builtin_inff(); best.index = -1;
+    for (uint32_t i = 0; i < n; ++i) sphere_test(spheres[i], (int)i, O, D, dbl_a, four_a, best);
     if (best.index >= 0) {
         const float t = best.num / dbl_a;
         if (t > 0.0f && t < closest) { closest = t; index = best.index; }
@@ -725,7 +774,8 @@ __device__ __forceinline__ bool path_step(Path& s, const RtParams& p, const Scen
     const bool last = s.bounce >= p.bounces;
     n_rays++;
     float tS = FLT_MAX; int iS = -1;                        // TraceRay (Renderer.cpp:231-301)
-    trace_spheres(p, s.O, s.D, tS, iS);
+    if (RT_SPHERE_LDS_LOOP && in_lds) trace_spheres_lds(lds.spheres, p.n_spheres, s.O, s.D, tS, iS);
+    else trace_spheres(p, s.O, s.D, tS, iS);
     Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
     return shade_hit<RT_MODE_SPHERES, in_lds>(s, p, lds, primary_id, first, last, tS, iS, th);
 }
@@ -1604,16 +1654,19 @@ struct PathPool {
 template <int MODE, bool STATS, bool ORDERED>
 __device__ __forceinline__ void tree_body(const RtParams& p)
 {
-    __shared__ SceneLds lds;                                // not used: tree scenes read the closest-hit tables from HBM
-    __shared__ PathPool pool;
+    __shared__ SceneLds lds;                                // tree scenes read the closest-hit tables from HBM; only the sphere loop of
+    __shared__ PathPool pool;                               // the mixed mode reads its table from here (trace_spheres_lds)
     // the counting kernels keep every path in the lane that started it (their per-wave clocks and trip counts describe the plain walk)
     constexpr bool SHARE = RT_SHARE != 0 && !STATS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool spheres_in_lds = RT_SPHERE_LDS_LOOP && MODE == RT_MODE_BOTH && p.n_spheres <= RT_LDS_SPHERES;
+    if (spheres_in_lds)
+        for (uint32_t i = threadIdx.x; i < p.n_spheres; i += blockDim.x) lds.spheres[i] = p.spheres[i];
     if (SHARE) {
         if (threadIdx.x == 0) { pool.lock = 0u; pool.count = 0u; pool.hungry = 0u; pool.busy = blockDim.x >> 6; }
-        __syncthreads();
     }
+    if (SHARE || MODE == RT_MODE_BOTH) __syncthreads();
     const bool sharing = SHARE && p.resume == 0u;           // a resume launch only finishes the parked paths
     bool waiting = false;                                   // wave-uniform: this wave is counted in pool.hungry, not in pool.busy
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
@@ -1842,7 +1895,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 s.bounce++;
                 if (p.first_hit_mode != 1u) n_rays++;       // (the launch that only stores primary hits is not a Render: its rays are counted by the launches that use them)
                 tS = FLT_MAX; iS = -1;
-                if (MODE == RT_MODE_BOTH && p.first_hit_mode != 1u) trace_spheres(p, s.O, s.D, tS, iS);
+                if (MODE == RT_MODE_BOTH && p.first_hit_mode != 1u) {
+                    if (spheres_in_lds) trace_spheres_lds(lds.spheres, p.n_spheres, s.O, s.D, tS, iS);
+                    else trace_spheres(p, s.O, s.D, tS, iS);
+                }
                 if (have_hit || end == 0u) phase = PH_SHADE;
                 else {
                     winvD = f3(1.0f / s.D.x, 1.0f / s.D.y, 1.0f / s.D.z);          // Renderer.cpp:151
