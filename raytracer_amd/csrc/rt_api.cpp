@@ -146,6 +146,7 @@ struct rt_ctx {
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
     float root_center[3] = {0.0f, 0.0f, 0.0f};                       // see RtParams
     float tie_box[3] = {0.0f, 0.0f, 0.0f}, tie_ulp = 0.0f, tie_rel = 0.0f, tie_abs = 0.0f;
+    bool slab_plain = false;                                         // see RtParams
     bool park_min_forced = false;
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
@@ -229,6 +230,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.first_hits = nullptr; p.first_hit_mode = 0u;
     p.slice_leave = c->n_nodes >= RT_LARGE_TREE ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
     for (int a = 0; a < 3; ++a) { p.root_center[a] = c->root_center[a]; p.tie_box[a] = c->tie_box[a]; }
+    p.slab_plain = c->slab_plain ? 1u : 0u;
     p.tie_ulp = c->tie_ulp; p.tie_rel = c->tie_rel; p.tie_abs = c->tie_abs;
 }
 
@@ -665,12 +667,15 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     {
         // the near-tie distance of the front-to-back walk (RtParams::tie_*)
         double reach[3] = {0.0, 0.0, 0.0}, mag[3] = {0.0, 0.0, 0.0};
+        bool bounded = true;                               // no box reaches beyond 2^60 (nor holds a NaN): RtParams::slab_plain
         for (uint32_t n = 0; n < N; ++n)
             for (int a = 0; a < 3; ++a) {
                 const double ce = kd->center[3 * (size_t)n + a], ex = std::fabs((double)kd->extent[3 * (size_t)n + a]);
                 reach[a] = std::max(reach[a], std::fabs(ce - (double)kd->center[a]) + ex);
                 mag[a] = std::max(mag[a], std::fabs(ce) + ex);
+                if (!(std::fabs(ce) + ex <= 0x1p60)) bounded = false;
             }
+        c->slab_plain = bounded;
         double k_max = 0.0, e_max = 0.0;                   // max |e1|_1 |e2|_1 and the longest edge component over the triangles
         for (uint32_t t = 0; t < c->n_tris; ++t) {
             const uint32_t* ix = &c->h_tris[3 * (size_t)t];

@@ -60,6 +60,9 @@
 #ifndef RT_KEEP
 #define RT_KEEP 2                  /* paths a wave keeps for itself when it gives others away */
 #endif
+#ifndef RT_PLAIN_SLAB
+#define RT_PLAIN_SLAB 1            /* 0 compiles the short form of the box test out (A/B measurements) */
+#endif
 #define RT_POOL_SLOTS 16           // paths the pool holds while they change waves
 #define RT_POOL_WORDS 38           // 32-bit words of one path's state
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
@@ -114,6 +117,7 @@ struct RtParams {
     uint32_t n_units_main;                 // ... of which the first n_units_main are the 8x2 strips of the owned bands; the rest are 16x1
                                            // strips of the rows that border an owned band (`halo`: the 3x3 filter reads them under a tile split)
     uint32_t halo;
+    uint32_t slab_plain;                   // every node box has |centre| + extent <= 2^60 on each axis (see slab_plain_ray)
     uint32_t* work_heads;                  // RT_WORK_HEADS ticket counters (RT_HEAD_STRIDE words apart), zero before every trace launch
     int32_t  use_ace;
     uint32_t fuse_resolve;                  // sphere trace kernel: each workgroup also resolves its share of the image

@@ -326,17 +326,46 @@ __device__ __forceinline__ void trace_spheres(const RtParams& p, F3 O, F3 D, flo
 
 // ---- KD tree: KDTreeCPU.cpp:640-708 over the preorder/skip layout; Intersections.cpp:23-94 ------------------------
 // Intersections::aabbIntersect (Intersections.cpp:23-47) with compare+select min/max in the reference's operand order.
-__device__ __forceinline__ bool slab_test(float4 n0, float4 n1, F3 O, F3 invD, float& tNear)
+// PLAIN: for a ray and a tree that cannot produce a NaN or an infinity in any of these operations (see slab_plain_ray): all twelve
+// values are finite, so the hardware minimum / maximum return the operand the compare+select forms return -- up to the sign of a
+// zero, which none of the comparisons below (nor the pruning test on tNear) can tell -- in 8 instructions instead of 28.
+template <bool PLAIN>
+__device__ __forceinline__ bool slab_test_t(float4 n0, float4 n1, F3 O, F3 invD, float& tNear)
 {
     F3 l1 = (f3(n0.x, n0.y, n0.z) - O) * invD;
     F3 l2 = f3(n1.x, n1.y, n1.z) * invD;
     F3 tMin = l1 - l2;
     F3 tMax = l1 + l2;
-    float t2x = sel_max(tMin.x, tMax.x), t2y = sel_max(tMin.y, tMax.y), t2z = sel_max(tMin.z, tMax.z);
-    float tFar = sel_min(sel_min(t2x, t2y), t2z);
-    float t1x = sel_min(tMin.x, tMax.x), t1y = sel_min(tMin.y, tMax.y), t1z = sel_min(tMin.z, tMax.z);
-    tNear = sel_max(sel_max(t1x, t1y), t1z);
+    float tFar;
+    if (PLAIN) {
+        // (the instructions themselves: the compiler's fminf / fmaxf first pass every operand through a quieting v_max x, x)
+        float hx, hy, hz, lx, ly, lz;
+        asm("v_max_f32 %0, %1, %2" : "=v"(hx) : "v"(tMin.x), "v"(tMax.x));
+        asm("v_max_f32 %0, %1, %2" : "=v"(hy) : "v"(tMin.y), "v"(tMax.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(hz) : "v"(tMin.z), "v"(tMax.z));
+        asm("v_min_f32 %0, %1, %2" : "=v"(lx) : "v"(tMin.x), "v"(tMax.x));
+        asm("v_min_f32 %0, %1, %2" : "=v"(ly) : "v"(tMin.y), "v"(tMax.y));
+        asm("v_min_f32 %0, %1, %2" : "=v"(lz) : "v"(tMin.z), "v"(tMax.z));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tFar) : "v"(hx), "v"(hy), "v"(hz));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tNear) : "v"(lx), "v"(ly), "v"(lz));
+    } else {
+        float t2x = sel_max(tMin.x, tMax.x), t2y = sel_max(tMin.y, tMax.y), t2z = sel_max(tMin.z, tMax.z);
+        tFar = sel_min(sel_min(t2x, t2y), t2z);
+        float t1x = sel_min(tMin.x, tMax.x), t1y = sel_min(tMin.y, tMax.y), t1z = sel_min(tMin.z, tMax.z);
+        tNear = sel_max(sel_max(t1x, t1y), t1z);
+    }
     return !(tFar < 0.0f) && !(tNear > tFar);
+}
+__device__ __forceinline__ bool slab_test(float4 n0, float4 n1, F3 O, F3 invD, float& tNear) { return slab_test_t<false>(n0, n1, O, invD, tNear); }
+
+// Can the slab test of this ray against any box of the tree meet a NaN or an infinity?  Not when every box has |centre| + extent
+// <= 2^60 per axis (RtParams::slab_plain, checked at upload), the origin lies within 2^60 and every component of the inverse
+// direction within 2^64: then |centre - origin| <= 2^61, both products stay below 2^125 and their sum and difference below 2^126.
+// (An inverse direction is infinite for a zero AND for a denormal direction component; NaNs fail the comparisons.)
+__device__ __forceinline__ bool slab_plain_ray(F3 O, F3 invD)
+{
+    return fabsf(invD.x) <= 0x1p64f && fabsf(invD.y) <= 0x1p64f && fabsf(invD.z) <= 0x1p64f
+        && fabsf(O.x) <= 0x1p60f && fabsf(O.y) <= 0x1p60f && fabsf(O.z) <= 0x1p60f;
 }
 
 // Intersections::triIntersect (Intersections.cpp:56-94) on a pre-gathered record (e1, e2 formed at upload).
@@ -465,7 +494,7 @@ __device__ __forceinline__ float wave_min(float v)            // wave-uniform re
 // found here in the same leaf with the same arithmetic, so the closest hit is the same, with ties again resolved to the
 // smallest record index.  `start`: the node cursor of the walk; hit / best_rec: its closest hit so far, in and out (all
 // arguments wave-uniform).  `cap`: a distance beyond which no hit matters (see tree_body), FLT_MAX = none.
-template <bool ORDERED>
+template <bool ORDERED, bool PLAIN>
 __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
                                                  float tol, float cap, Hit& hit, uint32_t& best_rec)
 {
@@ -482,7 +511,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
         float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
         if (valid) { n0 = nodes[2 * (size_t)j]; n1 = nodes[2 * (size_t)j + 1]; }
         float tNear;
-        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const bool box = slab_test_t<PLAIN>(n0, n1, O, invD, tNear);     // (lanes past the end of the array test a box of zeros: as finite)
         const bool descend = valid && box && !(tNear > fminf(ORDERED && RT_NEAR_TIES ? t_prune + (tol + p.tie_rel * t_prune) : t_prune, cap));
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
@@ -1658,6 +1687,11 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     __shared__ PathPool pool;                               // the mixed mode reads its table from here (trace_spheres_lds)
     // the counting kernels keep every path in the lane that started it (their per-wave clocks and trip counts describe the plain walk)
     constexpr bool SHARE = RT_SHARE != 0 && !STATS;
+    // The timed front-to-back kernels make their box tests in the short form (slab_test_t<true>), which is exact for rays that
+    // cannot meet a NaN in them (slab_plain_ray).  The few other rays (a zero or denormal direction component in y or z, an origin
+    // beyond 2^60, a tree with boxes beyond 2^60) never enter that walk: the wave makes the reference's own walk for them, with the
+    // compare+select forms, as it does for near ties.
+    constexpr bool PLAIN = RT_PLAIN_SLAB != 0 && ORDERED && RT_NEAR_TIES != 0 && !STATS;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const bool spheres_in_lds = RT_SPHERE_LDS_LOOP && MODE == RT_MODE_BOTH && p.n_spheres <= RT_LDS_SPHERES;
@@ -1921,6 +1955,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     }
                     if (MODE == RT_MODE_BOTH && ORDERED) wprune = sphere_cap();
                     phase = PH_WALK;
+                    if (PLAIN && !(p.slab_plain != 0u && slab_plain_ray(s.O, winvD))) phase = PH_REDO;     // (see PLAIN)
                 }
             } else if (begin && phase == PH_BEGIN) {
                 phase = PH_SHADE;                           // no bounces at all: the path ends with its initial colour
@@ -1970,7 +2005,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         const float4* nodes = p.nodes + 2 * ((size_t)__shfl(woct, src) * (size_t)p.n_nodes);
                         const float tol = ORDERED ? __shfl(wtol, src) : 0.0f;
                         const float cap = __shfl(sphere_cap(), src);
-                        const bool near_tie = walk_cooperative<ORDERED>(p, nodes, O, D, invD, first, lane, tol, cap, h, best);
+                        const bool near_tie = walk_cooperative<ORDERED, PLAIN>(p, nodes, O, D, invD, first, lane, tol, cap, h, best);
                         if ((int)lane == src) {
                             th = h; wbest = best; wnode = end;
                             wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + p.tie_rel * h.t) : h.t;
@@ -1996,7 +2031,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         wsteps++;
                         if (STATS) n_nodes++;
                         float tNear;
-                        const bool box = slab_test(n0, n1, s.O, winvD, tNear);
+                        const bool box = slab_test_t<PLAIN>(n0, n1, s.O, winvD, tNear);
                         // "if (dist_aabb_near > t) return false; if (intersects_aabb) ..." -- dist is FLT_MAX on a box miss
                         const bool descend = box && !(tNear > (ORDERED ? wprune : th.t));
                         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);

@@ -924,7 +924,7 @@ def test_first_hit_reuse_under_a_tile_split_with_the_filter(rt, orc, renderer):
 @pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("mode", [0, 2])
 def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order, counting):
-    """Host-supplied directions with +0 / -0 planted in x, y, z (alone and combined) on scattered pixels, next to the default
+    """Host-supplied directions with +0 / -0 (and denormal or tiny components) planted in x, y, z (alone and combined) on scattered pixels, next to the default
     camera's own +0 column: the pre-pass (x == +0 primaries), the wave-cooperative walk (x == -0, and any bounce) and the
     ordinary walk (zeros in y / z only) must all reproduce the reference's visited sets and hits.  With the counting kernels
     (every unit traced from the root, node and triangle counters compared) and with the kernels that are timed (units that are
@@ -935,10 +935,10 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order, 
     cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h).copy()
     rng = np.random.default_rng(5)
-    pick = rng.choice(w * h, 90, replace=False)
+    pick = rng.choice(w * h, 130, replace=False)
     pz, nz = np.float32(0.0), np.float32(-0.0)
     for i, px in enumerate(pick):
-        k = i % 9
+        k = i % 13
         if k == 0: dirs[px, 0] = pz
         elif k == 1: dirs[px, 0] = nz
         elif k == 2: dirs[px, 1] = pz
@@ -947,7 +947,13 @@ def test_zero_direction_components_all_patterns(rt, orc, renderer, mode, order, 
         elif k == 5: dirs[px, 0] = nz; dirs[px, 2] = pz
         elif k == 6: dirs[px, 1] = nz; dirs[px, 2] = nz
         elif k == 7: dirs[px, 0] = pz; dirs[px, 1] = nz; dirs[px, 2] = pz          # a ray going nowhere
-        else: dirs[px, 0] = pz; dirs[px] *= np.float32(3.0)                        # not unit length
+        elif k == 8: dirs[px, 0] = pz; dirs[px] *= np.float32(3.0)                 # not unit length
+        # components whose inverse is infinite or huge without being zero: the walk's box tests can meet inf - inf there as well
+        # (the timed front-to-back kernels hand such rays to the reference's own walk)
+        elif k == 9: dirs[px, 1] = np.float32(1e-40)                               # denormal: 1 / y = inf
+        elif k == 10: dirs[px, 2] = np.float32(-1e-30)                             # 1 / z = -1e30: products overflow
+        elif k == 11: dirs[px, 1] = np.float32(3e-20)                              # 1 / y just above 2^64
+        else: dirs[px, 2] = np.float32(1e-19)                                      # 1 / z just below 2^64
     st = renderer.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = mode, 5, True, False, True, 1337
     st.TraversalOrder = order
