@@ -667,7 +667,7 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     {
         // the near-tie distance of the front-to-back walk (RtParams::tie_*)
         double reach[3] = {0.0, 0.0, 0.0}, mag[3] = {0.0, 0.0, 0.0};
-        bool bounded = true;                               // no box reaches beyond 2^60 (nor holds a NaN): RtParams::slab_plain
+        bool bounded = true;                               // no box beyond 2^60, no triangle with |e1|_1 |e2|_1 beyond 2^56, no NaN: RtParams::slab_plain
         for (uint32_t n = 0; n < N; ++n)
             for (int a = 0; a < 3; ++a) {
                 const double ce = kd->center[3 * (size_t)n + a], ex = std::fabs((double)kd->extent[3 * (size_t)n + a]);
@@ -675,7 +675,6 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
                 mag[a] = std::max(mag[a], std::fabs(ce) + ex);
                 if (!(std::fabs(ce) + ex <= 0x1p60)) bounded = false;
             }
-        c->slab_plain = bounded;
         double k_max = 0.0, e_max = 0.0;                   // max |e1|_1 |e2|_1 and the longest edge component over the triangles
         for (uint32_t t = 0; t < c->n_tris; ++t) {
             const uint32_t* ix = &c->h_tris[3 * (size_t)t];
@@ -686,7 +685,9 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
                 n1 += d1; n2 += d2; e_max = std::max(e_max, std::max(d1, d2));
             }
             k_max = std::max(k_max, n1 * n2);
+            if (!(n1 * n2 <= 0x1p56)) bounded = false;     // (also a NaN among the vertices)
         }
+        c->slab_plain = bounded;
         const double u = 5.9604644775390625e-8, K = k_max / 1e-5;
         double scale = 1.0;                                // RT_TIE_SCALE=<x> scales the distance (experiments: below 1 the guarantee is void)
         if (const char* e = getenv("RT_TIE_SCALE")) { const double v = atof(e); if (v > 0.0) scale = v; }

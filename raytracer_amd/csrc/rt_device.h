@@ -117,7 +117,7 @@ struct RtParams {
     uint32_t n_units_main;                 // ... of which the first n_units_main are the 8x2 strips of the owned bands; the rest are 16x1
                                            // strips of the rows that border an owned band (`halo`: the 3x3 filter reads them under a tile split)
     uint32_t halo;
-    uint32_t slab_plain;                   // every node box has |centre| + extent <= 2^60 on each axis (see slab_plain_ray)
+    uint32_t slab_plain;                   // every node box has |centre| + extent <= 2^60 on each axis and every triangle |e1|_1 |e2|_1 <= 2^56 (see slab_plain_ray)
     uint32_t* work_heads;                  // RT_WORK_HEADS ticket counters (RT_HEAD_STRIDE words apart), zero before every trace launch
     int32_t  use_ace;
     uint32_t fuse_resolve;                  // sphere trace kernel: each workgroup also resolves its share of the image

@@ -60,6 +60,16 @@ __device__ __forceinline__ float sqrt_rn(float x)
 #ifndef RT_FAST_RSQRT
 #define RT_FAST_RSQRT 1
 #endif
+// 1.0f / d, correctly rounded, for 2^-64 <= |d| <= 2^64: the compiler's expansion of that division with the operand scaling and
+// the special-case pass left out, neither of which does anything in this range (its first quotient 1 * r is r itself).
+__device__ __forceinline__ float rcp_unscaled(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+}
+
 __device__ __forceinline__ float rsqrt_rn(float x)
 {
 #if RT_FAST_RSQRT
@@ -68,10 +78,7 @@ __device__ __forceinline__ float rsqrt_rn(float x)
     const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
     float d = (0.0f >= r_below) ? below : s;
     d = (0.0f < r_above) ? above : d;
-    float r = __builtin_amdgcn_rcpf(d);
-    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    float q = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
+    float q = rcp_unscaled(d);
     const bool general = !(x >= 0x1p-96f && x <= FLT_MAX);
     if (__ballot(general) != 0ull) {
         float y = x;
@@ -362,20 +369,27 @@ __device__ __forceinline__ bool slab_test(float4 n0, float4 n1, F3 O, F3 invD, f
 // <= 2^60 per axis (RtParams::slab_plain, checked at upload), the origin lies within 2^60 and every component of the inverse
 // direction within 2^64: then |centre - origin| <= 2^61, both products stay below 2^125 and their sum and difference below 2^126.
 // (An inverse direction is infinite for a zero AND for a denormal direction component; NaNs fail the comparisons.)
+// Nor can the triangle test's determinant a = e1 . (D x e2) leave the range in which the short form of 1 / a is exact: the
+// direction's components lie within 2 (inverse >= 1/2) and |e1|_1 |e2|_1 <= 2^56 for every triangle of the mesh (the same flag), so
+// |a| <= 2 |D|_inf |e1|_1 |e2|_1 <= 2^58.
 __device__ __forceinline__ bool slab_plain_ray(F3 O, F3 invD)
 {
     return fabsf(invD.x) <= 0x1p64f && fabsf(invD.y) <= 0x1p64f && fabsf(invD.z) <= 0x1p64f
+        && fabsf(invD.x) >= 0.5f && fabsf(invD.y) >= 0.5f && fabsf(invD.z) >= 0.5f
         && fabsf(O.x) <= 0x1p60f && fabsf(O.y) <= 0x1p60f && fabsf(O.z) <= 0x1p60f;
 }
 
 // Intersections::triIntersect (Intersections.cpp:56-94) on a pre-gathered record (e1, e2 formed at upload).
-__device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, F3 D, float& tt, float& u, float& v)
+// PLAIN: for a ray and a mesh whose determinants stay below 2^58 (see slab_plain_ray).  The quotient 1 / a is used only where
+// |a| >= 1e-5, and for 1e-5 <= |a| <= 2^58 the short form of the division gives its bits.
+template <bool PLAIN>
+__device__ __forceinline__ bool tri_test_t(float4 r0, float4 r1, float4 r2, F3 O, F3 D, float& tt, float& u, float& v)
 {
     F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
     F3 h = cross3(D, e2);
     float a = dot3(e1, h);
     bool ok = !(a > -0.00001f && a < 0.00001f);
-    float f = 1.0f / a;
+    float f = PLAIN ? rcp_unscaled(a) : 1.0f / a;
     F3 s = O - v0;
     u = f * dot3(s, h);
     ok = ok && !(u < 0.0f || u > 1.0f);
@@ -384,6 +398,10 @@ __device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, 
     ok = ok && !(v < 0.0f || u + v > 1.0f);
     tt = f * dot3(e2, q);
     return ok && (tt > 0.00001f);
+}
+__device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, F3 D, float& tt, float& u, float& v)
+{
+    return tri_test_t<false>(r0, r1, r2, O, D, tt, u, v);
 }
 
 // A ray with direction.x == 0 exactly has an infinite inverse there, and the slab test then yields NaN for every box on one
@@ -547,7 +565,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
                 const uint32_t group_ends = (uint32_t)(ends >> (lane & 48u)) & 0xFFFFu;
                 const bool counts = open && rec_index < p.n_refs && (group_ends & ((1u << (lane & 15u)) - 1u)) == 0u;
                 float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v) && counts) {
+                if (tri_test_t<PLAIN>(r0, r1, r2, O, D, tt, u, v) && counts) {
                     const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
                     if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + p.tie_rel * fminf(tt, t)) near_tie = true;
                     if (tt < t || (tt == t && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
@@ -2046,7 +2064,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         if (STATS) n_tris++;
                         const uint32_t tag = __float_as_uint(r2.y);
                         float tt, u, v;
-                        if (tri_test(r0, r1, r2, s.O, s.D, tt, u, v)) {
+                        if (tri_test_t<PLAIN>(r0, r1, r2, s.O, s.D, tt, u, v)) {
                             const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
                             if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + p.tie_rel * fminf(tt, th.t)) wflag = true;
                             if (tt < th.t || (ORDERED && tt == th.t && wrec < wbest)) {
