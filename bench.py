@@ -255,6 +255,8 @@ def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=Non
         out["roofline_frac"] = flops / (kernel_ms_per_frame / 1e3) / 1e12 / PEAK_VALU_NOFMA_TFLOPS
     elif bytes_per_frame:
         out["roofline_frac"] = bytes_per_frame / (kernel_ms_per_frame / 1e3) / 1e9 / PEAK_HBM_GBS
+        out["roofline_note"] = ("algorithmic bytes of the walk against the HBM peak; the tree data is served mostly by L1 / L2 / Infinity Cache "
+                                "in launches of 16 Renders, so this can pass 1 (profiles/traffic.json has the bytes that reach HBM per launch)")
     return out
 
 
