@@ -228,7 +228,13 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.park_queue_count = c->d_park_queue_count.ptr; p.park_queue_cap = rt_ctx::kParkQueueCap;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
     p.first_hits = nullptr; p.first_hit_mode = 0u;
-    p.slice_leave = c->n_nodes >= RT_LARGE_TREE ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
+    // (measured: mesh-only scenes with a large tree, and their launches of several Renders, gain 2-4 % from the shorter slices; with
+    // spheres and mesh together the lanes that leave a slice run the sphere loop and the shading next, and the fuller batches of
+    // longer slices are worth 3 %)
+    p.slice_leave = c->settings.scene_mode != RT_SCENE_BOTH && (c->n_nodes >= RT_LARGE_TREE || n_frames > 1u) ? RT_SLICE_LEAVE_LARGE : RT_SLICE_LEAVE;
+    // tuning knob: RT_SLICE_LEAVE=<1..3> (quarters of a slice's walkers that are left when it ends)
+    static const int slice_leave_env = [] { const char* e = getenv("RT_SLICE_LEAVE"); return e ? atoi(e) : 0; }();
+    if (slice_leave_env >= 1 && slice_leave_env <= 3) p.slice_leave = (uint32_t)slice_leave_env;
     for (int a = 0; a < 3; ++a) { p.root_center[a] = c->root_center[a]; p.tie_box[a] = c->tie_box[a]; }
     p.slab_plain = c->slab_plain ? 1u : 0u;
     p.tie_ulp = c->tie_ulp; p.tie_rel = c->tie_rel; p.tie_abs = c->tie_abs;

@@ -42,8 +42,8 @@
 #define RT_SLICE_LEAVE 2           /* a walk slice ends when this many quarters of its walkers are left ... */
 #endif
 #ifndef RT_SLICE_LEAVE_LARGE
-#define RT_SLICE_LEAVE_LARGE 3     /* ... in a tree of at least RT_LARGE_TREE nodes (walks there are long and alike: shorter slices keep
-                                      more lanes walking; measured 10 M triangles -2 %, 70 k triangles +2 %) */
+#define RT_SLICE_LEAVE_LARGE 3     /* ... in a mesh-only scene with a tree of at least RT_LARGE_TREE nodes, or a launch of several Renders (walks
+                                      there are long and alike: shorter slices keep more lanes walking; the host chooses, see fill_params) */
 #endif
 #define RT_LARGE_TREE (1u << 18)
 #ifndef RT_COOP_LANES
