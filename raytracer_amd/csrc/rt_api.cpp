@@ -147,6 +147,9 @@ struct rt_ctx {
     float root_center[3] = {0.0f, 0.0f, 0.0f};                       // see RtParams
     float tie_box[3] = {0.0f, 0.0f, 0.0f}, tie_ulp = 0.0f, tie_rel = 0.0f, tie_abs = 0.0f;
     bool slab_plain = false;                                         // see RtParams
+    double mesh_mag = 0.0, mesh_emax = 0.0;                          // largest |coordinate| of a node box, longest edge component of a triangle
+    double host_dir_max = 1.0;                                       // largest |component| of the directions the host supplied
+    bool tests_may_overflow = false;                                 // see tri_tests_stay_finite (set per launch)
     bool park_min_forced = false;
     uint32_t park_min_nodes = RT_PARK_MIN_NODES;   // RT_PARK_MIN_NODES=<n> in the environment overrides it (tests park in small trees)
     bool kd_partition = false;           // every two-child node of the uploaded tree splits its box in two along one axis
@@ -694,6 +697,8 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             if (!(n1 * n2 <= 0x1p56)) bounded = false;     // (also a NaN among the vertices)
         }
         c->slab_plain = bounded;
+        c->mesh_mag = std::max(mag[0], std::max(mag[1], mag[2])); c->mesh_emax = e_max;
+        if (!bounded) c->mesh_mag = HUGE_VAL;              // (a NaN among the boxes or vertices)
         const double u = 5.9604644775390625e-8, K = k_max / 1e-5;
         double scale = 1.0;                                // RT_TIE_SCALE=<x> scales the distance (experiments: below 1 the guarantee is void)
         if (const char* e = getenv("RT_TIE_SCALE")) { const double v = atof(e); if (v > 0.0) scale = v; }
@@ -772,7 +777,12 @@ int rt_set_ray_dirs(rt_ctx* c, const float* xyz, size_t n)
     if (!xyz) { if (c->use_host_dirs) { c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; } return RT_OK; }
     if (!c->width || n != (size_t)c->width * c->height) return fail(c, RT_E_ARG, "rt_set_ray_dirs: %zu directions for a %ux%u frame", n, c->width, c->height);
     std::vector<float4> packed(n);
-    for (size_t i = 0; i < n; ++i) packed[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+    double dmax = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        packed[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+        for (int a = 0; a < 3; ++a) { const double v = std::fabs((double)xyz[3 * i + a]); if (!(v <= dmax)) dmax = v == v ? v : HUGE_VAL; }
+    }
+    c->host_dir_max = dmax;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_dirs.ptr, packed.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     c->use_host_dirs = true; c->dirs_dirty = false; c->columns_dirty = true;
@@ -880,6 +890,21 @@ int trace_grid(rt_ctx* c, int mode, bool stats, bool ordered, uint32_t n_units, 
 
 namespace {
 
+// Can a dot product of triIntersect overflow for some ray of this scene?  With e the longest edge component, M the largest
+// coordinate, origins within S = max(|camera|, M) + M and direction components within Dm, its intermediate values stay below
+// 6 Dm e^2, 6 S Dm e and 6 S e^2, and u, v, t below 1e5 times that.  Where they can overflow, a triangle test can succeed at
+// t = +inf, which KDTreeCPU::intersect reports as a hit of triangle 0 (see RT_HIT_DETECTED in rt_kernels.hip): the kernels that walk
+// the tree ray by ray reproduce that; the whole-chip kernels for rays with direction.x == 0 (column pre-pass, parked rays) keep
+// (t, record) keys and do not, so such a scene does without them and its waves walk those rays themselves.
+bool tri_tests_stay_finite(const rt_ctx* c)
+{
+    const double Dm = c->use_host_dirs ? std::max(1.0, c->host_dir_max) : 1.0;
+    double O = c->mesh_mag;
+    for (int a = 0; a < 3; ++a) O = std::max(O, std::fabs((double)c->cam_pos[a]));
+    const double S = O + c->mesh_mag, e = c->mesh_emax;
+    return 6e5 * S * e * std::max(e, Dm) < 1e37 && 6.0 * Dm * e * e < 1e37;     // (false for NaNs too)
+}
+
 // One launch of the trace kernel over the units of `p` and, in trees large enough for parking, the rounds that finish the paths
 // it parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a glass sphere that sits on
 // the camera's x).  Their hits by whole-chip kernels, family by family, then the rest of those paths by a small launch of the
@@ -892,6 +917,7 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
     // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
     // the rare walk by a wave, except in large trees.
     if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
+    if (c->tests_may_overflow) p.park_min_nodes = 0xFFFFFFFFu;          // (see tri_tests_stay_finite)
     const bool parking = tree && c->n_nodes >= p.park_min_nodes;
     if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
     // the unit tickets of tree scenes start at zero for every launch that draws units
@@ -969,7 +995,8 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // events: [pre, start) = what precedes the trace kernel on mesh scenes (the column pre-pass when the camera has direction.x == +0
     // pixels, the launch that stores first hits), [start, stop) = the trace kernel
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
-    const bool columns = tree && c->n_columns && (!reuse || store_first);     // (stored hits answer the column rays too)
+    c->tests_may_overflow = tree && !tri_tests_stay_finite(c);
+    const bool columns = tree && c->n_columns && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
     // Which triangle a column ray hits depends on the camera, the directions, the bands and the tree only: the pre-pass runs when
     // one of those changed and its result (the best hit per column ray) is kept.  The counting kernels always run it: their
     // counters describe what the reference's walk costs for these rays.

@@ -247,6 +247,16 @@ __device__ __forceinline__ F3 camera_dir(const RtParams& p, uint32_t x, uint32_t
 }
 
 struct Hit { float t; int32_t id; float u, v; };
+// KDTreeCPU::intersect reports a hit as soon as ANY triangle test of a visited leaf succeeds ("intersection_detected",
+// KDTreeCPU.cpp:666-690), also when the test's distance never passed "tmp_t < t" -- which, with t starting at FLT_MAX, takes a
+// successful test at t = +inf (its dot products overflowed) or at FLT_MAX exactly.  TraceRay then shades triangle 0 at distance
+// FLT_MAX with u = v = 0, the initial values of its variables (Renderer.cpp:274-286).  Hit::id = RT_HIT_DETECTED marks that state of
+// a walk (a test succeeded, no distance accepted yet); resolve_detected turns it into what TraceRay sees.
+constexpr int32_t RT_HIT_DETECTED = -2;
+__device__ __forceinline__ void resolve_detected(Hit& h)
+{
+    if (h.id == RT_HIT_DETECTED) { h.id = 0; h.t = FLT_MAX; h.u = 0.0f; h.v = 0.0f; }
+}
 constexpr uint32_t RT_NO_REC = 0xFFFFFFFFu;           // "no leaf record": a walk's cursor is at a node
 
 // ---- spheres: Renderer.cpp:243-271 ------------------------------------------------------------------------------
@@ -423,7 +433,7 @@ __device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, 
     int32_t tri = -1;
     uint32_t base = 0, killed_to = 0;                       // wave-uniform: window start; nodes below killed_to are unreachable
     const uint32_t end = p.n_nodes;
-    bool t_dependent = false;
+    bool t_dependent = false, detected = false;
     while (base < end) {
         const uint32_t j = base + lane;
         const bool valid = j < end;
@@ -455,7 +465,10 @@ __device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, 
                 if (STATS) n_tris_tested++;
                 const uint32_t tag = __float_as_uint(r2.y);
                 float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; best_rec = rec_index; }
+                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+                    if (tt < t) { t = tt; tri = (int32_t)(tag & 0x7FFFFFFFu); hu = u; hv = v; best_rec = rec_index; }
+                    else detected = true;
+                }
                 ++rec_index;
                 if (tag & 0x80000000u) break;
             }
@@ -472,6 +485,7 @@ __device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, 
         const int32_t otri = __shfl_xor(tri, off); const float ou = __shfl_xor(hu, off), ov = __shfl_xor(hv, off);
         if (ot < t || (ot == t && orec < best_rec)) { t = ot; best_rec = orec; tri = otri; hu = ou; hv = ov; }
     }
+    if (tri < 0 && __ballot(detected) != 0ull) tri = RT_HIT_DETECTED;
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
     return true;
 }
@@ -516,9 +530,9 @@ template <bool ORDERED, bool PLAIN>
 __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4* nodes, F3 O, F3 D, F3 invD, uint32_t start, uint32_t lane,
                                                  float tol, float cap, Hit& hit, uint32_t& best_rec)
 {
-    bool near_tie = false;
+    bool near_tie = false, detected = hit.id == RT_HIT_DETECTED;
     float t = hit.t, hu = hit.u, hv = hit.v;                // lane-local closest hit; every lane starts from the ray's
-    int32_t tri = hit.id;
+    int32_t tri = hit.id >= 0 ? hit.id : -1;
     uint32_t rec_best = best_rec;
     float t_prune = hit.t;                                  // wave-uniform
     uint32_t base = start, killed_to = start;
@@ -568,7 +582,8 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
                 if (tri_test_t<PLAIN>(r0, r1, r2, O, D, tt, u, v) && counts) {
                     const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
                     if (ORDERED && RT_NEAR_TIES && id != tri && fabsf(tt - t) <= tol + p.tie_rel * fminf(tt, t)) near_tie = true;
-                    if (tt < t || (tt == t && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
+                    if (tt < t || (tt == t && tri >= 0 && rec_index < rec_best)) { t = tt; tri = id; hu = u; hv = v; rec_best = rec_index; }
+                    else if (tri < 0) detected = true;
                 }
                 if (group_ends != 0u) open = false;
                 rec_index += 16u;
@@ -589,6 +604,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
     }
     // a lane whose own closest hit is another triangle within that distance of the wave's: a near tie across lanes
     if (ORDERED && RT_NEAR_TIES && tri_own != tri && fabsf(t_own - t) <= tol + p.tie_rel * fminf(t_own, t)) near_tie = true;
+    if (tri < 0 && __ballot(detected) != 0ull) tri = RT_HIT_DETECTED;
     hit.t = t; hit.id = tri; hit.u = hu; hit.v = hv;
     best_rec = rec_best;
     return __ballot(near_tie) != 0ull;
@@ -607,6 +623,7 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
 {
     float t_cur = FLT_MAX, hu = 0.0f, hv = 0.0f;            // wave-uniform
     int32_t tri = -1;
+    bool detected = false;                                  // wave-uniform
     uint32_t base = 0, killed_to = 0;
     const uint32_t end = p.n_nodes;
     while (base < end) {
@@ -624,7 +641,7 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
         const bool reached = valid && j >= limit;           // exact for the nodes that are not rejected, which is all that is asked below
         float lt = t_cur, lu = 0.0f, lv = 0.0f;
         int32_t ltri = -1;
-        bool closer = false;
+        bool closer = false, succeeded = false;
         uint32_t tested = 0;
         if (reached && descend && leaf_first >= 0) {
             const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
@@ -635,7 +652,10 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
                 ++tested;
                 const uint32_t tag = __float_as_uint(r2.y);
                 float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v) && tt < lt) { lt = tt; ltri = (int32_t)(tag & 0x7FFFFFFFu); lu = u; lv = v; closer = true; }
+                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
+                    succeeded = true;
+                    if (tt < lt) { lt = tt; ltri = (int32_t)(tag & 0x7FFFFFFFu); lu = u; lv = v; closer = true; }
+                }
                 if (tag & 0x80000000u) break;
                 r0 = q0; r1 = q1; r2 = q2;
             }
@@ -650,6 +670,7 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
             tri = __builtin_amdgcn_readlane(ltri, f);
             upto = (uint32_t)f + 1u;
         }
+        if (__ballot(succeeded && lane < upto) != 0ull) detected = true;     // (only the lanes whose decisions stand)
         if (STATS) {
             uint32_t before = __shfl_up(pm, 1);             // rejected subtrees' ends over the lanes before this one
             if (lane == 0) before = 0u;
@@ -661,6 +682,7 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
         base += upto;
         if (killed_to > base) base = killed_to;
     }
+    if (tri < 0 && detected) tri = RT_HIT_DETECTED;
     hit.t = t_cur; hit.id = tri; hit.u = hu; hit.v = hv;
 }
 
@@ -2067,10 +2089,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         if (tri_test_t<PLAIN>(r0, r1, r2, s.O, s.D, tt, u, v)) {
                             const int32_t id = (int32_t)(tag & 0x7FFFFFFFu);
                             if (ORDERED && RT_NEAR_TIES && id != th.id && fabsf(tt - th.t) <= wtol + p.tie_rel * fminf(tt, th.t)) wflag = true;
-                            if (tt < th.t || (ORDERED && tt == th.t && wrec < wbest)) {
+                            if (tt < th.t || (ORDERED && tt == th.t && th.id >= 0 && wrec < wbest)) {
                                 th.t = tt; th.id = id; th.u = u; th.v = v; wbest = wrec;
                                 wprune = fminf(RT_NEAR_TIES ? tt + (wtol + p.tie_rel * tt) : tt, sphere_cap());
-                            }
+                            } else if (th.id < 0) th.id = RT_HIT_DETECTED;      // (a test that succeeded at t = +inf)
                         }
                         const bool more = (tag & 0x80000000u) == 0u;
                         wrec = more ? wrec + 1u : RT_NO_REC;
@@ -2097,6 +2119,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         }
 
         // ---- the lanes whose ray is traced: the rest of the bounce (Renderer.cpp:160-226)
+        if (phase == PH_SHADE) resolve_detected(th);
         if (phase == PH_SHADE && p.first_hit_mode == 1u) {
             // only the primary ray's mesh hit is wanted: kept for the launches that follow
             if (p.bounces != 0u) p.first_hits[pixel] = make_float4(th.t, th.u, th.v, __uint_as_float((uint32_t)th.id));

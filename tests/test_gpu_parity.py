@@ -249,15 +249,20 @@ def test_mesh_orders_agree_from_other_viewpoints(rt, orc, renderer, side):
     assert (want["ids"] >= 0).sum() > 1000
 
 
+@pytest.mark.parametrize("counting", [False, True], ids=["timed-kernels", "counting-kernels"])
+@pytest.mark.parametrize("log2_scale", [33, 45, 61])
 @pytest.mark.parametrize("order", ORDERS)
-def test_scene_beyond_the_bounds_of_the_short_box_test(rt, orc, renderer, order):
+def test_scenes_of_absurd_size(rt, orc, renderer, order, log2_scale, counting):
     """The timed front-to-back kernels test boxes with the hardware min / max and divide by the determinant in a short form, which
     is only exact while no operation can overflow: trees within 2^60, triangles with |e1|_1 |e2|_1 <= 2^56.  A scene scaled by 2^33
-    (camera included) has triangles beyond the second bound: every ray has to take the reference's own walk instead -- and must
-    still give the oracle's ids and sums, bit for bit, in both orders.  (Far beyond that, from about 2^40, the dot products of
-    triIntersect itself overflow to t = +inf; see the numerics contract for what the reference does then.)"""
+    (camera included) has triangles beyond the second bound: every ray has to take the reference's own walk instead.  From about
+    2^40 the dot products of triIntersect itself overflow: tests succeed at t = +inf, which KDTreeCPU::intersect reports as a hit
+    ("intersection_detected") although no distance was accepted, and TraceRay then shades triangle 0 at FLT_MAX; at 2^45 that is a
+    part of the pixels, at 2^61 (outside both bounds) every pixel the mesh covers.  Ids, sums and image must be the oracle's, bit
+    for bit, in both orders, with zeros planted in direction.x as well (such rays are walked by their wave here: the whole-chip
+    kernels are not used where tests can overflow)."""
     from raytracer_amd import scenes
-    k = np.float32(2.0 ** 33)
+    k = np.float32(2.0 ** log2_scale)
     centre = np.array([0.0, 0.6, -0.8], np.float32)
     verts, tris, normals9, tri_mat, mesh_mats = scenes.cube_sphere(10, center=tuple(centre), radius=0.7)
     scene, osc = make_scene(rt, orc, mesh=((verts * k).astype(np.float32), tris, normals9, tri_mat, mesh_mats), spheres=False)
@@ -266,11 +271,13 @@ def test_scene_beyond_the_bounds_of_the_short_box_test(rt, orc, renderer, order)
     # ray directions of the unscaled camera (the inverse view matrix of a camera 10^10 away loses its rotation to cancellation), origin scaled
     cam0 = rt.Camera(70.0, 0.05, 100.0); cam0.SetPose((centre + np.float32(1.9) * d).astype(np.float32), (-d).astype(np.float32)); cam0.OnResize(w, h)
     dirs = orc.ray_dirs(cam0.GetInverseProjection(), cam0.GetInverseView(), w, h).copy()
+    for i, px in enumerate(np.random.default_rng(11).choice(w * h, 40, replace=False)):
+        dirs[px, 0] = np.float32(0.0) if i % 2 else np.float32(-0.0)
     cam = rt.Camera(70.0, 0.05, 100.0); cam.SetPose(((centre + np.float32(1.9) * d) * k).astype(np.float32), (-d).astype(np.float32)); cam.OnResize(w, h)
     st = renderer.GetSettings()
     st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = 0, 4, True, False, True, 1337
     st.TraversalOrder = order
-    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(False); renderer.reset_counters()
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.set_stats(counting); renderer.reset_counters()
     renderer.upload(scene, cam)
     renderer.set_ray_dirs(dirs)
     try:
@@ -283,8 +290,9 @@ def test_scene_beyond_the_bounds_of_the_short_box_test(rt, orc, renderer, order)
                    img=renderer.GetImage().data.reshape(-1, 4), cnt=renderer.read_counters())
         assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=cnt))
         assert (ids >= 0).sum() > 500
+        if log2_scale == 61: assert (ids[ids >= 0] == 0x40000000).all()             # nothing but triangle 0, "detected"
     finally:
-        renderer.set_ray_dirs(None); st.TraversalOrder = 0
+        renderer.set_ray_dirs(None); renderer.set_stats(False); st.TraversalOrder = 0
 
 
 @pytest.mark.parametrize("shift", [0.0, 1e-6, 3e-4], ids=["coincident", "within-rounding", "apart"])
