@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Randomised parity probe (run on the GPU box from the repo root): scenes with unusual parameters -- radii of zero, negative or
+huge size, cameras inside spheres, roughness beyond 1, refraction indices below 1 or negative, emission of 1e30, materials with
+albedo 0, meshes next to or around the camera, zero or one bounce -- rendered by the library and by the oracle; primary ids,
+accumulation and image must agree bit for bit.  python tools/fuzz_parity.py [cases] [seed]"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import raytracer_amd as rt
+from raytracer_amd import scenes
+from oracle import orc
+
+bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+pick = lambda *xs: xs[rng.integers(len(xs))]
+
+
+def random_materials(n):
+    m = np.zeros(n, scenes.MATERIAL_DTYPE)
+    for i in range(n):
+        m[i]["albedo"] = pick(rng.random(3), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0), rng.random(3) * 3.0, (1e-30, 0.5, 0.0))
+        m[i]["emission"] = pick((0.0, 0.0, 0.0), rng.random(3) * 5.0, (1e30, 1e30, 0.0), (0.0, 1e-40, 3.0))
+        m[i]["roughness"] = pick(0.0, 1.0, rng.random(), 1.7, -0.5)
+        m[i]["transparency"] = pick(0.0, 0.0, 1.0, 0.3, -1.0)
+        m[i]["ior"] = pick(1.0, 1.1, 1.5, 0.7, 2.5, 0.0, -1.3, 1e-20)
+    return m
+
+
+def random_spheres(n, n_mats):
+    s = np.zeros(n, scenes.SPHERE_DTYPE)
+    for i in range(n):
+        c = rng.normal(size=3) * pick(0.5, 2.0, 20.0)
+        s[i] = (np.float32(c[0]), np.float32(c[1] + 1.0), np.float32(c[2]), np.float32(pick(0.3, 1.0, 0.0, -0.7, 50.0, 1000.0, 1e-6, rng.random() * 2)),
+                rng.integers(n_mats))
+    return s
+
+
+r = rt.Renderer(0)
+failures = 0
+for case in range(n_cases):
+    mode = int(pick(1, 1, 0, 2))
+    n_mats = int(rng.integers(1, 9))
+    mats = random_materials(n_mats)
+    scene = rt.Scene(); osc = orc.Scene()
+    scene.spheres = random_spheres(int(rng.integers(0 if mode == 2 else 1, 14)), n_mats) if mode != 0 else scenes.default_spheres()[:0]
+    if mode == 1 and rng.random() < 0.3:
+        scene.spheres = np.concatenate([scenes.default_spheres(), scene.spheres]); scene.spheres["material"] %= n_mats
+    if mode != 1:
+        n = int(pick(6, 14, 24))
+        verts, tris, normals9, tri_mat, _mm = pick(lambda: scenes.displaced_grid(n), lambda: scenes.cube_sphere(max(4, n // 2), center=(0.0, 1.0, 1.5), radius=2.5),
+                                                   lambda: scenes.cube_sphere(max(4, n // 2)))()
+        if rng.random() < 0.3: normals9 = (normals9 * np.float32(pick(0.0, -1.0, 7.0))).astype(np.float32)      # unnormalised / zero / flipped normals
+        tri_mat = rng.integers(0, n_mats, len(tris)).astype(np.uint32)
+        scene.set_triangles(verts, tris, normals9, tri_mat, nthreads=4)
+        osc.set_mesh(verts, tris, normals9, tri_mat); osc.import_kd(scene.kd_tree.arrays())
+    scene.materials = mats
+    osc.set_spheres(scene.spheres); osc.set_materials(mats)
+    w, h = int(pick(64, 96, 33)), int(pick(48, 17, 64))
+    cam = rt.Camera(float(pick(70.0, 45.0, 120.0)), 0.05, 100.0)
+    if rng.random() < 0.5:
+        pos = (rng.normal(size=3) * pick(0.3, 3.0)).astype(np.float32); fwd = rng.normal(size=3).astype(np.float32); fwd /= np.linalg.norm(fwd)
+        if abs(fwd[1]) > 0.95: fwd = np.array([0.0, -0.1, -1.0], np.float32) / np.float32(np.sqrt(1.01))
+        cam.SetPose(pos, fwd.astype(np.float32))
+    cam.OnResize(w, h)
+    bounces, frames = int(pick(0, 1, 3, 5, 9)), int(pick(1, 2, 5))
+    use_ace, aa, seed = bool(rng.random() < 0.7), bool(rng.random() < 0.2), int(pick(1337, 0, 4242424242))
+    order = int(pick(0, 1, 2))
+    per_launch = int(pick(1, 1, 2, 16))                       # Renders per launch (rt_render_frames)
+    reuse = bool(mode != 1 and rng.random() < 0.3)            # kept first hits
+    st = r.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = mode, bounces, use_ace, aa, True, seed, order
+    st.ReuseFirstHits = reuse
+    r.OnResize(w, h); r.ResetFrameIndex(); r.record_ids(True); r.reset_counters()
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
+    cnt = orc.Counters()
+    ost = orc.Settings(1, mode, int(use_ace), int(aa), bounces)
+    try:
+        f = 1
+        for _launch in range(frames):
+            r.Render(scene, cam, frames=per_launch)
+            for _k in range(per_launch):
+                osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, seed=seed, primary_ids=ids if f == 1 else None, counters=cnt, nthreads=8)
+                f += 1
+        g_ids, g_acc, g_img, g_cnt = r.read_primary_ids().ravel(), r.read_accum().reshape(-1, 3), r.GetImage().data.reshape(-1, 4), r.read_counters()
+        bad = []
+        if not np.array_equal(g_ids, ids): bad.append("ids: %d differ" % (g_ids != ids).sum())
+        if not np.array_equal(bits(g_acc), bits(acc)): bad.append("accumulation: %d values differ" % (bits(g_acc) != bits(acc)).sum())
+        if not np.array_equal(bits(g_img), bits(img)): bad.append("image: %d values differ" % (bits(g_img) != bits(img)).sum())
+        if g_cnt.rays != cnt.rays: bad.append("rays %d vs %d" % (g_cnt.rays, cnt.rays))
+    except Exception as e:                                   # a refused scene is reported, not a crash of the probe
+        bad = ["%s: %s" % (type(e).__name__, e)]
+    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d" % (
+        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse)
+    if bad:
+        failures += 1
+        print("MISMATCH", desc, "|", "; ".join(bad), flush=True)
+    else:
+        print("ok      ", desc, flush=True)
+    st.TraversalOrder = 0; st.ReuseFirstHits = False
+print("%d of %d cases differ" % (failures, n_cases))
+sys.exit(1 if failures else 0)
