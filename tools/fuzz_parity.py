@@ -40,10 +40,11 @@ r = rt.Renderer(0)
 failures = 0
 for case in range(n_cases):
     mode = int(pick(1, 1, 0, 2))
-    n_mats = int(rng.integers(1, 9))
+    n_mats = int(pick(rng.integers(1, 9), rng.integers(1, 9), 40, 140))      # (beyond 32 / 128: other table paths in the kernels)
     mats = random_materials(n_mats)
     scene = rt.Scene(); osc = orc.Scene()
-    scene.spheres = random_spheres(int(rng.integers(0 if mode == 2 else 1, 14)), n_mats) if mode != 0 else scenes.default_spheres()[:0]
+    n_sph = int(pick(rng.integers(0 if mode == 2 else 1, 14), rng.integers(0 if mode == 2 else 1, 14), 33, 45, 150))
+    scene.spheres = random_spheres(n_sph, n_mats) if mode != 0 else scenes.default_spheres()[:0]
     if mode == 1 and rng.random() < 0.3:
         scene.spheres = np.concatenate([scenes.default_spheres(), scene.spheres]); scene.spheres["material"] %= n_mats
     if mode != 1:
