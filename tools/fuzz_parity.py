@@ -74,11 +74,25 @@ for case in range(n_cases):
     st.ReuseFirstHits = reuse
     r.OnResize(w, h); r.ResetFrameIndex(); r.record_ids(True); r.reset_counters()
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    host_dirs = rng.random() < 0.25                           # directions from the host, some of them odd: zeros, denormals, not unit length
+    if host_dirs:
+        dirs = dirs.copy()
+        for px in rng.choice(w * h, 60, replace=False):
+            k = int(rng.integers(8))
+            if k == 0: dirs[px, rng.integers(3)] = np.float32(pick(0.0, -0.0))
+            elif k == 1: dirs[px, rng.integers(3)] = np.float32(pick(1e-40, -1e-41, 1e-30, 3e-20))
+            elif k == 2: dirs[px] *= np.float32(pick(3.0, 0.01, 1e6, 1e-6))
+            elif k == 3: dirs[px] = (0.0, 0.0, 0.0)
+            elif k == 4: dirs[px] = np.float32(pick(1.0, -1.0)) * np.eye(3, dtype=np.float32)[rng.integers(3)]
+            elif k == 5: dirs[px, 0] = np.float32(0.0); dirs[px, 1] = np.float32(-0.0)
+            else: dirs[px] = rng.normal(size=3).astype(np.float32)
     acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
     cnt = orc.Counters()
     ost = orc.Settings(1, mode, int(use_ace), int(aa), bounces)
     try:
         f = 1
+        if host_dirs:
+            r.upload(scene, cam); r.set_ray_dirs(dirs)
         for _launch in range(frames):
             r.Render(scene, cam, frames=per_launch)
             for _k in range(per_launch):
@@ -92,13 +106,14 @@ for case in range(n_cases):
         if g_cnt.rays != cnt.rays: bad.append("rays %d vs %d" % (g_cnt.rays, cnt.rays))
     except Exception as e:                                   # a refused scene is reported, not a crash of the probe
         bad = ["%s: %s" % (type(e).__name__, e)]
-    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d" % (
-        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse)
+    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d" % (
+        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs)
     if bad:
         failures += 1
         print("MISMATCH", desc, "|", "; ".join(bad), flush=True)
     else:
         print("ok      ", desc, flush=True)
     st.TraversalOrder = 0; st.ReuseFirstHits = False
+    if host_dirs: r.set_ray_dirs(None)
 print("%d of %d cases differ" % (failures, n_cases))
 sys.exit(1 if failures else 0)
