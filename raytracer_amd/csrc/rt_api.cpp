@@ -172,6 +172,14 @@ int fail(rt_ctx* c, int code, const char* fmt, ...)
     do { hipError_t e_ = (expr);                                                                     \
          if (e_ != hipSuccess) return fail((c), RT_E_HIP, "%s: %s", #expr, hipGetErrorString(e_)); } while (0)
 
+// A kernel launch; with RT_DEBUG_SYNC=1 in the environment the stream is drained right after it, so that a fault is reported
+// with the launch that caused it instead of at some later call (debugging aid: every launch then costs a host round trip).
+static const bool g_debug_sync = [] { const char* e = getenv("RT_DEBUG_SYNC"); return e && *e && *e != '0'; }();
+#define LAUNCH_TRY(c, expr)                                                                           \
+    do { HIP_TRY(c, expr);                                                                           \
+         if (g_debug_sync) { hipError_t s_ = hipStreamSynchronize((c)->stream);                      \
+             if (s_ != hipSuccess) return fail((c), RT_E_HIP, "after %s: %s", #expr, hipGetErrorString(s_)); } } while (0)
+
 struct DeviceGuard {
     int prev = -1; bool ok = false;
     explicit DeviceGuard(int dev) { ok = hipGetDevice(&prev) == hipSuccess && hipSetDevice(dev) == hipSuccess; }
@@ -630,6 +638,8 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     // the walk reads RT_WALK_FETCH consecutive float4 at its cursor (three nodes or two leaf records): pad the ends
     HIP_TRY(c, c->d_nodes.resize(8 * 2 * (size_t)M + RT_WALK_FETCH));
     HIP_TRY(c, c->d_leafrecs.resize((recs.empty() ? 3 : recs.size()) + RT_WALK_FETCH));
+    HIP_TRY(c, hipMemset(c->d_nodes.ptr + 8 * 2 * (size_t)M, 0, RT_WALK_FETCH * sizeof(float4)));            // (what is read there is never used)
+    HIP_TRY(c, hipMemset(c->d_leafrecs.ptr + (recs.empty() ? 3 : recs.size()), 0, RT_WALK_FETCH * sizeof(float4)));
 
     // Eight node arrays, one per sign pattern of a ray direction (bit a set: direction[a] < 0).  Array o is the tree in the
     // preorder that walks, at every two-child node, the child on the side a ray of that pattern comes from first.  Array 0
@@ -803,7 +813,7 @@ namespace {
 int ensure_dirs(rt_ctx* c, const RtParams& p)
 {
     if (!c->dirs_dirty || c->use_host_dirs) return RT_OK;
-    HIP_TRY(c, rt_launch_raygen(&p, c->stream));
+    LAUNCH_TRY(c, rt_launch_raygen(&p, c->stream));
     c->dirs_dirty = false; c->columns_dirty = true;
     return RT_OK;
 }
@@ -822,7 +832,7 @@ int ensure_columns(rt_ctx* c, RtParams& p)
     if (c->halo_in_columns != (p.halo != 0u)) c->columns_dirty = true;      // the rows bordering the bands joined or left the frame
     if (!c->columns_dirty) return RT_OK;
     c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_in_columns = p.halo != 0u;
-    HIP_TRY(c, rt_launch_column_collect(&p, c->stream));
+    LAUNCH_TRY(c, rt_launch_column_collect(&p, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->columns_dirty = false;
@@ -847,14 +857,14 @@ int ensure_units(rt_ctx* c, RtParams& p, bool ordered)
         if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(4));
         p.unit_empty_out = c->d_unit_empty.ptr; p.unit_list_out = c->d_unit_list.ptr; p.unit_counts_out = c->d_unit_counts.ptr;
         HIP_TRY(c, hipMemsetAsync(c->d_unit_counts.ptr, 0, 4 * sizeof(uint32_t), c->stream));
-        HIP_TRY(c, rt_launch_units_classify(&p, c->stream));
+        LAUNCH_TRY(c, rt_launch_units_classify(&p, c->stream));
         uint32_t counts[2] = {0, 0};
         HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr, sizeof counts, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->n_list = counts[0]; c->empty_pixels = counts[1];
         // where the primary walks of the listed units may start, for the walk order in use
         p.n_list = c->n_list; p.unit_entry_out = c->d_unit_entry.ptr; p.entry_ordered = ordered ? 1u : 0u;
-        HIP_TRY(c, rt_launch_units_entry(&p, c->stream));
+        LAUNCH_TRY(c, rt_launch_units_entry(&p, c->stream));
         HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr + 2, sizeof counts, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->entry_nodes = counts[0]; c->entry_tris = counts[1];
@@ -922,7 +932,7 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
     if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
     // the unit tickets of tree scenes start at zero for every launch that draws units
     if (tree) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
+    LAUNCH_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     if (stop) HIP_TRY(c, hipEventRecord(stop, c->stream));
     if (!parking) return RT_OK;
     uint32_t parked = 0;
@@ -935,10 +945,10 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
         q.resume_count = c->d_park_count.ptr + cur; q.resume_paths = c->d_park_paths.ptr + (size_t)cur * RT_PARK_SLOTS * RT_PARK_WORDS;
         q.park_count = c->d_park_count.ptr + (1 - cur); q.park_paths = c->d_park_paths.ptr + (size_t)(1 - cur) * RT_PARK_SLOTS * RT_PARK_WORDS;
         HIP_TRY(c, hipMemsetAsync(q.park_count, 0, sizeof(uint32_t), c->stream));
-        HIP_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
+        LAUNCH_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
         q.resume = last ? 2u : 1u;
         const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
-        HIP_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
+        LAUNCH_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
         if (last) break;
         cur = 1 - cur;
         HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));
@@ -1004,7 +1014,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     c->ev_has_pre[ev] = prepass || store_first;
     if (c->ev_has_pre[ev]) HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
     if (prepass) {
-        HIP_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
+        LAUNCH_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
         c->column_cache = true;
     }
     if (!columns) p.column_best = nullptr;
@@ -1031,9 +1041,9 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     }
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
-    if (tree) HIP_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
-    else if (!fused) HIP_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
-    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
+    if (tree) LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
+    else if (!fused) LAUNCH_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
     return RT_OK;
 }
 
@@ -1069,8 +1079,8 @@ int rt_resolve(rt_ctx* c, uint32_t frame_index)
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;
     c->latest_in_back = false;
-    HIP_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
-    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
+    LAUNCH_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;
 }
 
@@ -1289,8 +1299,8 @@ __attribute__((visibility("hidden"))) int rt_internal_resolve_from(rt_ctx* c, co
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;
     c->latest_in_back = false;
-    HIP_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
-    if (c->settings.anti_aliasing) HIP_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
+    LAUNCH_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
+    if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;
 }
 

@@ -1995,7 +1995,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     }
                     if (MODE == RT_MODE_BOTH && ORDERED) wprune = sphere_cap();
                     phase = PH_WALK;
-                    if (PLAIN && !(p.slab_plain != 0u && slab_plain_ray(s.O, winvD))) phase = PH_REDO;     // (see PLAIN)
+                    // A unit whose primary rays pass the root box and then miss everything alike has the END of the node array as
+                    // its entry: the walk is over before it starts (a trip would read whatever lies behind the array as a node).
+                    if (wnode >= end) phase = PH_SHADE;
+                    else if (PLAIN && !(p.slab_plain != 0u && slab_plain_ray(s.O, winvD))) phase = PH_REDO;     // (see PLAIN)
                 }
             } else if (begin && phase == PH_BEGIN) {
                 phase = PH_SHADE;                           // no bounces at all: the path ends with its initial colour

@@ -89,6 +89,7 @@ for case in range(n_cases):
     acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
     cnt = orc.Counters()
     ost = orc.Settings(1, mode, int(use_ace), int(aa), bounces)
+    if os.environ.get("FUZZ_VERBOSE"): print("start    case %d" % case, flush=True)
     try:
         f = 1
         if host_dirs:
@@ -104,8 +105,9 @@ for case in range(n_cases):
         if not np.array_equal(bits(g_acc), bits(acc)): bad.append("accumulation: %d values differ" % (bits(g_acc) != bits(acc)).sum())
         if not np.array_equal(bits(g_img), bits(img)): bad.append("image: %d values differ" % (bits(g_img) != bits(img)).sum())
         if g_cnt.rays != cnt.rays: bad.append("rays %d vs %d" % (g_cnt.rays, cnt.rays))
-    except Exception as e:                                   # a refused scene is reported, not a crash of the probe
-        bad = ["%s: %s" % (type(e).__name__, e)]
+    except Exception as e:                                   # an error from the library (a refused scene, a failed GPU call) ends the probe:
+        print("ERROR    case %d: %s: %s" % (case, type(e).__name__, e), flush=True)       # nothing more is started on the GPU after it
+        sys.exit(2)
     desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d" % (
         case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs)
     if bad:
