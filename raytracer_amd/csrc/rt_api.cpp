@@ -224,7 +224,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.primary_ids = c->record_ids ? c->d_ids.ptr : nullptr;
     p.work_heads = c->d_work_heads.ptr;
     p.counters = c->d_counters.ptr; p.wave_clock = c->wave_clock_on ? c->d_wave_clock.ptr : nullptr; p.column_stats = c->d_column_stats.ptr;
-    p.n_refs = c->n_refs; p.column_cap = rt_ctx::kColumnCap;
+    p.n_refs = c->n_refs; p.n_tris = c->n_tris; p.column_cap = rt_ctx::kColumnCap;
     p.column_count = c->d_column_count.ptr; p.column_pixels = c->d_column_pixels.ptr;
     p.column_best = c->d_column_best.ptr; p.column_flags = c->d_column_flags.ptr; p.reached = c->d_reached.ptr; p.rec_leaf = c->d_rec_leaf.ptr;
     p.column_dirs = c->d_column_dirs.ptr; p.column_block = c->d_column_block.ptr;
@@ -350,7 +350,7 @@ rt_ctx* rt_create(int device_id)
         c->d_park_paths.resize(2 * (size_t)RT_PARK_SLOTS * RT_PARK_WORDS) != hipSuccess || c->d_park_best.resize(RT_PARK_SLOTS) != hipSuccess ||
         c->d_work_heads.resize(RT_WORK_HEADS * RT_HEAD_STRIDE) != hipSuccess ||
         hipMemset(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t)) != hipSuccess ||
-        c->d_column_stats.resize(4) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 32) != hipSuccess ||
+        c->d_column_stats.resize(8) != hipSuccess || hipMemset(c->d_column_stats.ptr, 0, 64) != hipSuccess ||
         c->d_column_count.resize(1) != hipSuccess || c->d_column_flags.resize(1) != hipSuccess ||
         c->d_column_pixels.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_best.resize(rt_ctx::kColumnCap) != hipSuccess ||
         c->d_column_dirs.resize(rt_ctx::kColumnCap) != hipSuccess || c->d_column_queue_count.resize(1) != hipSuccess ||
@@ -1235,8 +1235,9 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     for (size_t i = 0; i < h.size(); i += 4) {
         out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
     }
-    unsigned long long cs[4] = {0, 0, 0, 0};
+    unsigned long long cs[5] = {0, 0, 0, 0, 0};
     HIP_TRY(c, hipMemcpy(cs, c->d_column_stats.ptr, sizeof cs, hipMemcpyDeviceToHost));
+    if (cs[4]) return fail(c, RT_E_STATE, "rt_read_counters: a kernel's index test failed (code %llu, see RT_CHECKED)", cs[4]);
     out->prepass_nodes = cs[0]; out->prepass_tris = cs[1]; out->near_ties = cs[2]; out->primary_hits_reused = cs[3];
     out->nodes_visited += cs[0]; out->tris_tested += cs[1];
     out->rays += c->host_rays; out->empty_unit_rays = c->host_rays; out->view_setups = c->view_setups;
@@ -1250,7 +1251,7 @@ int rt_reset_counters(rt_ctx* c)
     if (!c->d_counters.count) return RT_OK;
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 4 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
     c->host_rays = 0; c->view_setups = 0; c->host_entry_nodes = 0; c->host_entry_tris = 0;
     return RT_OK;
 }

@@ -63,6 +63,13 @@
 #ifndef RT_PLAIN_SLAB
 #define RT_PLAIN_SLAB 1            /* 0 compiles the short form of the box test out (A/B measurements) */
 #endif
+#ifndef RT_CHECKED
+#define RT_CHECKED 0               /* 1: the kernels test the indices their per-lane state machines carry (walk cursors, the triangle / sphere /
+                                      material of a hit, slots of parked and column rays) against their arrays before using them; a failed
+                                      test is recorded in column_stats[4], the index replaced by 0, and rt_read_counters reports it as an
+                                      error -- a fault of a state machine then shows as a message, not as a GPU memory fault (for the
+                                      randomised probe, tools/fuzz_parity.py) */
+#endif
 #define RT_POOL_SLOTS 16           // paths the pool holds while they change waves
 #define RT_POOL_WORDS 38           // 32-bit words of one path's state
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
@@ -111,7 +118,7 @@ struct RtParams {
     uint32_t frame_first, n_frames;
     uint32_t seed, bounces;
     uint32_t n_spheres, n_materials;
-    uint32_t n_nodes;
+    uint32_t n_nodes, n_tris;
     uint32_t band_index, band_count;       // screen-tile split: this context renders bands b*band_count + band_index
     uint32_t tile_rows, n_units;           // 8-row tile rows / RT_UNIT-pixel work units in the bands this context renders
     uint32_t n_units_main;                 // ... of which the first n_units_main are the 8x2 strips of the owned bands; the rest are 16x1
@@ -159,8 +166,9 @@ struct RtParams {
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
     unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop
-    unsigned long long* column_stats;       // 4: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
-                                            // reference's order because of a near tie; primary rays answered from first_hits
+    unsigned long long* column_stats;       // 8: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
+                                            // reference's order because of a near tie; primary rays answered from first_hits; [4] the
+                                            // largest code of a failed index test (RT_CHECKED builds, else 0)
     // primary rays with direction.x == +0 ("column rays"): numbered when directions change, resolved per frame by a pre-pass
     uint32_t  n_refs;                        // leaf records
     uint32_t  column_cap;

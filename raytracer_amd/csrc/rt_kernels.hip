@@ -414,6 +414,20 @@ __device__ __forceinline__ bool tri_test(float4 r0, float4 r1, float4 r2, F3 O, 
     return tri_test_t<false>(r0, r1, r2, O, D, tt, u, v);
 }
 
+// Index tests of the RT_CHECKED build (see rt_device.h): `index` if it lies below `count`, else 0 with `code` recorded.  Compiled
+// out otherwise.  Codes: 1 node cursor, 2 record cursor, 3 triangle of a hit, 4 sphere of a hit, 5 material, 6 column slot,
+// 7 / 9 record of a column / parked result, 8 slot of a resumed path, 10 entry node of a unit, 11 / 12 frame / pixel of a
+// radiance slot, 13 start of a cooperative walk, 14-16 first record of a leaf in the three whole-wave walks.
+__device__ __forceinline__ uint32_t checked(const RtParams& p, uint32_t index, uint32_t count, uint32_t code)
+{
+#if RT_CHECKED
+    if (!(index < count)) { if (p.column_stats) atomicMax(p.column_stats + 4, (unsigned long long)code); return 0u; }
+#else
+    (void)p; (void)count; (void)code;
+#endif
+    return index;
+}
+
 // A ray with direction.x == 0 exactly has an infinite inverse there, and the slab test then yields NaN for every box on one
 // side of the origin (inf - inf): such a box counts as hit with t_near = NaN and "NaN > t" never prunes it.  (A zero in y or z
 // does not stick: the reference's select order drops those NaNs and the ray is pruned as usual.)  Every
@@ -458,7 +472,7 @@ __device__ __forceinline__ bool trace_mesh_cooperative(const RtParams& p, F3 O, 
         if (STATS && reached) n_nodes_visited++;
         if (reached && box && leaf_first >= 0) {
             uint32_t rec_index = (uint32_t)leaf_first;
-            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
+            const float4* rec = p.leafrecs + 3 * (size_t)checked(p, (uint32_t)leaf_first, p.n_refs, 14);
             for (;;) {
                 const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                 rec += 3;
@@ -535,8 +549,9 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
     int32_t tri = hit.id >= 0 ? hit.id : -1;
     uint32_t rec_best = best_rec;
     float t_prune = hit.t;                                  // wave-uniform
-    uint32_t base = start, killed_to = start;
     const uint32_t end = p.n_nodes;
+    start = checked(p, start, end + 1u, 13);
+    uint32_t base = start, killed_to = start;
     while (base < end) {
         const uint32_t j = base + lane;
         const bool valid = j < end;
@@ -564,7 +579,7 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
                 if (leaves != 0ull) {
                     const int src = __ffsll((long long)leaves) - 1;
                     leaves &= leaves - 1ull;
-                    const uint32_t first = (uint32_t)__builtin_amdgcn_readlane(leaf_first, src);
+                    const uint32_t first = checked(p, (uint32_t)__builtin_amdgcn_readlane(leaf_first, src), p.n_refs, 15);
                     if ((lane >> 4) == g) group_first = first;
                 }
             }
@@ -644,7 +659,7 @@ __device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3
         bool closer = false, succeeded = false;
         uint32_t tested = 0;
         if (reached && descend && leaf_first >= 0) {
-            const float4* rec = p.leafrecs + 3 * (size_t)leaf_first;
+            const float4* rec = p.leafrecs + 3 * (size_t)checked(p, (uint32_t)leaf_first, p.n_refs, 16);
             float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
             for (;;) {
                 const float4 q0 = rec[3], q1 = rec[4], q2 = rec[5];
@@ -780,13 +795,14 @@ __device__ __forceinline__ bool shade_hit(Path& s, const RtParams& p, const Scen
     F3 P, N;
     uint32_t matIndex;
     if (MODE == RT_MODE_SPHERES || tS < th.t) {             // ClosestHitSphere (Renderer.cpp:303-317); a sphere hit has t < FLT_MAX
+        iS = (int)checked(p, (uint32_t)iS, p.n_spheres, 4);
         const float4 sp = in_lds ? lds.spheres[iS] : p.spheres[iS];      // per-lane index
         P = O + D * tS;
         N = normalize3(P - f3(sp.x, sp.y, sp.z));
         matIndex = in_lds ? lds.sphere_mat[iS] : p.sphere_mat[iS];
         if (primary_id && first) *primary_id = iS;
     } else {                                                // ClosestHitTriangle (Renderer.cpp:319-332)
-        const float4* sh = p.trishade + 3 * (size_t)th.id;
+        const float4* sh = p.trishade + 3 * (size_t)checked(p, (uint32_t)th.id, p.n_tris, 3);
         float4 s0 = sh[0], s1 = sh[1], s2 = sh[2];
         P = O + D * th.t;
         F3 nrm = (f3(s0.x, s0.y, s0.z) * ((1.0f - th.u) - th.v) + f3(s0.w, s1.x, s1.y) * th.u) + f3(s1.z, s1.w, s2.x) * th.v;
@@ -795,6 +811,7 @@ __device__ __forceinline__ bool shade_hit(Path& s, const RtParams& p, const Scen
         if (primary_id && first) *primary_id = RT_ID_TRI_BIT | th.id;
     }
 
+    matIndex = checked(p, matIndex, p.n_materials, 5);
     const float4 m0 = in_lds ? lds.materials[3 * matIndex] : p.materials[3 * matIndex];             // albedo.rgb, roughness
     const float4 m1 = in_lds ? lds.materials[3 * matIndex + 1] : p.materials[3 * matIndex + 1];     // emission.rgb, transparency
     bool hitInside = dot3(D, N) > 0.0f;
@@ -1909,9 +1926,9 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             bool unprunable = start && !have_hit && s.D.x == 0.0f;
             if (unprunable && s.bounce == 0 && s.column_slot != 0u && p.column_best && (*p.column_flags & 1u) == 0u) {
                 // primary column rays were resolved for the whole frame by the pre-pass: re-run the winning triangle test for u, v
-                const unsigned long long key = p.column_best[s.column_slot - 1u];
+                const unsigned long long key = p.column_best[checked(p, s.column_slot - 1u, p.column_cap, 6)];
                 if (key != ~0ull) {
-                    const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                    const float4* rec = p.leafrecs + 3 * (size_t)checked(p, (uint32_t)key, p.n_refs, 7);
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                     float tt, u, v;
                     tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
@@ -1923,10 +1940,10 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
             // a parked path comes back with its hit (unless a decision of its walk depended on t: then it is walked here)
             if (parked_hit_ready) {
                 parked_hit_ready = false;
-                if (unprunable && (p.park_flags[resume_slot] & 1u) == 0u) {
-                    const unsigned long long key = p.park_best[resume_slot];
+                if (unprunable && (p.park_flags[checked(p, resume_slot, RT_PARK_SLOTS, 8)] & 1u) == 0u) {
+                    const unsigned long long key = p.park_best[checked(p, resume_slot, RT_PARK_SLOTS, 8)];
                     if (key != ~0ull) {
-                        const float4* rec = p.leafrecs + 3 * (size_t)(uint32_t)key;
+                        const float4* rec = p.leafrecs + 3 * (size_t)checked(p, (uint32_t)key, p.n_refs, 9);
                         const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                         float tt, u, v;
                         tri_test(r0, r1, r2, s.O, s.D, tt, u, v);
@@ -1979,7 +1996,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     woct = 0;
                     if (ORDERED) woct = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
-                    if (MODE == RT_MODE_MESH && !STATS && s.bounce == 1u && p.unit_entry) wnode = p.unit_entry[pixel];   // (see RtParams::unit_entry)
+                    if (MODE == RT_MODE_MESH && !STATS && s.bounce == 1u && p.unit_entry) wnode = checked(p, p.unit_entry[pixel], end + 1u, 10);   // (see RtParams::unit_entry)
                     wprune = FLT_MAX; wflag = false;
                     if (ORDERED && RT_NEAR_TIES) {
                         // The part of the near-tie distance that does not grow with t (see RtParams::tie_*): the rounding of a box's
@@ -2066,7 +2083,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     // loads that a long walk is.
                     const bool at_node = wrec == RT_NO_REC;
                     // (the cursor is an index into arrays named by the kernel arguments, so these are global loads, not generic ones)
-                    const float4* a = at_node ? p.nodes + 2 * ((size_t)woct * (size_t)p.n_nodes + wnode) : p.leafrecs + 3 * (size_t)wrec;
+                    const float4* a = at_node ? p.nodes + 2 * ((size_t)woct * (size_t)p.n_nodes + checked(p, wnode, end, 1))
+                                              : p.leafrecs + 3 * (size_t)checked(p, wrec, p.n_refs, 2);
                     const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5];
                     static_assert(RT_WALK_FETCH == 6, "the walk reads six float4 per trip");
                     // returns true when the walk went down to the next node in memory
@@ -2139,7 +2157,8 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 if (id_out && p.bounces == 0) *id_out = -1;
                 // pixelColor of this Render: the resolve pass makes "m_AccumulationBuffer[pixelIndex] += pixelColor" of it, frame by
                 // frame.  The fourth component carries, from the counting kernels, the node + triangle steps of the path.
-                p.slots[(size_t)frame * plane + pixel] = make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, STATS ? (float)path_steps : 0.0f);
+                p.slots[(size_t)checked(p, frame, p.n_frames, 11) * plane + checked(p, pixel, plane, 12)] =
+                    make_float4(s.finalColor.x, s.finalColor.y, s.finalColor.z, STATS ? (float)path_steps : 0.0f);
                 phase = PH_IDLE;
                 path_steps = 0;
             }

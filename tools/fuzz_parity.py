@@ -2,7 +2,10 @@
 """Randomised parity probe (run on the GPU box from the repo root): scenes with unusual parameters -- radii of zero, negative or
 huge size, cameras inside spheres, roughness beyond 1, refraction indices below 1 or negative, emission of 1e30, materials with
 albedo 0, meshes next to or around the camera, zero or one bounce -- rendered by the library and by the oracle; primary ids,
-accumulation and image must agree bit for bit.  python tools/fuzz_parity.py [cases] [seed]"""
+accumulation and image must agree bit for bit.  python tools/fuzz_parity.py [cases] [seed]
+FUZZ_WIDE=1 widens the draw (larger meshes, frames of 1 x 1 to 130 x 70 pixels); the default draw stays as it is so that a seed
+keeps naming the same scenes.  Meant to run against a library built with -DRT_CHECKED=1 (tools/build_variant.sh), in which a
+state machine that leaves its arrays is reported as an error instead of faulting the GPU."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +17,7 @@ bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 pick = lambda *xs: xs[rng.integers(len(xs))]
+wide = bool(os.environ.get("FUZZ_WIDE"))
 
 
 def random_materials(n):
@@ -48,7 +52,7 @@ for case in range(n_cases):
     if mode == 1 and rng.random() < 0.3:
         scene.spheres = np.concatenate([scenes.default_spheres(), scene.spheres]); scene.spheres["material"] %= n_mats
     if mode != 1:
-        n = int(pick(6, 14, 24))
+        n = int(pick(6, 14, 24, 48, 80)) if wide else int(pick(6, 14, 24))
         verts, tris, normals9, tri_mat, _mm = pick(lambda: scenes.displaced_grid(n), lambda: scenes.cube_sphere(max(4, n // 2), center=(0.0, 1.0, 1.5), radius=2.5),
                                                    lambda: scenes.cube_sphere(max(4, n // 2)))()
         if rng.random() < 0.3: normals9 = (normals9 * np.float32(pick(0.0, -1.0, 7.0))).astype(np.float32)      # unnormalised / zero / flipped normals
@@ -57,7 +61,7 @@ for case in range(n_cases):
         osc.set_mesh(verts, tris, normals9, tri_mat); osc.import_kd(scene.kd_tree.arrays())
     scene.materials = mats
     osc.set_spheres(scene.spheres); osc.set_materials(mats)
-    w, h = int(pick(64, 96, 33)), int(pick(48, 17, 64))
+    w, h = (int(pick(64, 96, 33, 1, 130, 16)), int(pick(48, 17, 64, 1, 7, 70))) if wide else (int(pick(64, 96, 33)), int(pick(48, 17, 64)))
     cam = rt.Camera(float(pick(70.0, 45.0, 120.0)), 0.05, 100.0)
     if rng.random() < 0.5:
         pos = (rng.normal(size=3) * pick(0.3, 3.0)).astype(np.float32); fwd = rng.normal(size=3).astype(np.float32); fwd /= np.linalg.norm(fwd)
@@ -77,7 +81,7 @@ for case in range(n_cases):
     host_dirs = rng.random() < 0.25                           # directions from the host, some of them odd: zeros, denormals, not unit length
     if host_dirs:
         dirs = dirs.copy()
-        for px in rng.choice(w * h, 60, replace=False):
+        for px in rng.choice(w * h, min(60, w * h), replace=False):
             k = int(rng.integers(8))
             if k == 0: dirs[px, rng.integers(3)] = np.float32(pick(0.0, -0.0))
             elif k == 1: dirs[px, rng.integers(3)] = np.float32(pick(1e-40, -1e-41, 1e-30, 3e-20))
