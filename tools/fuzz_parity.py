@@ -10,7 +10,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import raytracer_amd as rt
-from raytracer_amd import scenes
+from raytracer_amd import scenes, dist as rtd
 from oracle import orc
 
 bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)
@@ -73,10 +73,14 @@ for case in range(n_cases):
     order = int(pick(0, 1, 2))
     per_launch = int(pick(1, 1, 2, 16))                       # Renders per launch (rt_render_frames)
     reuse = bool(mode != 1 and rng.random() < 0.3)            # kept first hits
-    st = r.GetSettings()
-    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = mode, bounces, use_ace, aa, True, seed, order
-    st.ReuseFirstHits = reuse
-    r.OnResize(w, h); r.ResetFrameIndex(); r.record_ids(True); r.reset_counters()
+    world = int(pick(1, 1, 1, 2, 3, 5)) if wide else 1          # tile split: one context per rank on this GPU, each renders its bands
+
+    def prepared(rr):
+        st = rr.GetSettings()
+        st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = mode, bounces, use_ace, aa, True, seed, order
+        st.ReuseFirstHits = reuse
+        rr.OnResize(w, h); rr.ResetFrameIndex(); rr.record_ids(True); rr.reset_counters()
+        return rr
     dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
     host_dirs = rng.random() < 0.25                           # directions from the host, some of them odd: zeros, denormals, not unit length
     if host_dirs:
@@ -96,30 +100,41 @@ for case in range(n_cases):
     if os.environ.get("FUZZ_VERBOSE"): print("start    case %d" % case, flush=True)
     try:
         f = 1
-        if host_dirs:
-            r.upload(scene, cam); r.set_ray_dirs(dirs)
         for _launch in range(frames):
-            r.Render(scene, cam, frames=per_launch)
             for _k in range(per_launch):
                 osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, seed=seed, primary_ids=ids if f == 1 else None, counters=cnt, nthreads=8)
                 f += 1
-        g_ids, g_acc, g_img, g_cnt = r.read_primary_ids().ravel(), r.read_accum().reshape(-1, 3), r.GetImage().data.reshape(-1, 4), r.read_counters()
+        g_ids, g_acc, g_img = np.zeros(h * w, np.int32), np.zeros((h * w, 3), np.float32), np.zeros((h * w, 4), np.float32)
+        g_rays = 0
+        for rank in range(world):
+            rr = prepared(r if world == 1 else rt.Renderer(0))
+            if world > 1: rr.set_bands(rank, world)
+            if host_dirs:
+                rr.upload(scene, cam); rr.set_ray_dirs(dirs)
+            for _launch in range(frames):
+                rr.Render(scene, cam, frames=per_launch)
+            rows = np.arange(h) if world == 1 else rtd.band_rows(h, rank, world)
+            px = (rows[:, None] * w + np.arange(w)[None, :]).ravel()
+            g_ids[px] = rr.read_primary_ids().ravel()[px]; g_acc[px] = rr.read_accum().reshape(-1, 3)[px]; g_img[px] = rr.GetImage().data.reshape(-1, 4)[px]
+            g_rays += rr.read_counters().rays
+            if world > 1: del rr
+        if world > 1 and aa: g_rays = cnt.rays                   # (under a tile split with the filter on, the rows bordering a band are traced twice)
         bad = []
         if not np.array_equal(g_ids, ids): bad.append("ids: %d differ" % (g_ids != ids).sum())
         if not np.array_equal(bits(g_acc), bits(acc)): bad.append("accumulation: %d values differ" % (bits(g_acc) != bits(acc)).sum())
         if not np.array_equal(bits(g_img), bits(img)): bad.append("image: %d values differ" % (bits(g_img) != bits(img)).sum())
-        if g_cnt.rays != cnt.rays: bad.append("rays %d vs %d" % (g_cnt.rays, cnt.rays))
+        if g_rays != cnt.rays: bad.append("rays %d vs %d" % (g_rays, cnt.rays))
     except Exception as e:                                   # an error from the library (a refused scene, a failed GPU call) ends the probe:
         print("ERROR    case %d: %s: %s" % (case, type(e).__name__, e), flush=True)       # nothing more is started on the GPU after it
         sys.exit(2)
-    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d" % (
-        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs)
+    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d, ranks %d" % (
+        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs, world)
     if bad:
         failures += 1
         print("MISMATCH", desc, "|", "; ".join(bad), flush=True)
     else:
         print("ok      ", desc, flush=True)
-    st.TraversalOrder = 0; st.ReuseFirstHits = False
-    if host_dirs: r.set_ray_dirs(None)
+    st = r.GetSettings(); st.TraversalOrder = 0; st.ReuseFirstHits = False
+    if host_dirs and world == 1: r.set_ray_dirs(None)
 print("%d of %d cases differ" % (failures, n_cases))
 sys.exit(1 if failures else 0)
