@@ -113,6 +113,29 @@ def test_binned_builder_matches_oracle_builder(orc, n, drop):
     assert mine["depth"] == theirs["depth"]
 
 
+def test_builder_at_a_size_where_its_threads_share_nodes_and_subtrees(orc):
+    """288,800 triangles: the root is split with its counting cut into chunks for all threads, the next levels are tasks of the
+    pool, whole subtrees below are built thread by thread and numbered in parallel.  One thread, five threads and the oracle's
+    naive restatement of KDTreeCPU::constructTreeStackless give the same tree, bit for bit."""
+    import raytracer_amd as rt
+    from raytracer_amd import scenes
+    verts, tris, normals9, tri_mat, _ = scenes.displaced_grid(380, x_range=(-15.0, 15.0), z_range=(-30.0, 0.0))
+    assert len(tris) >= 1 << 18
+    sc = orc.Scene(); sc.set_mesh(verts, tris, normals9, tri_mat); sc.build_kd()
+    theirs = sc.export_kd()
+    for threads in (1, 5):
+        mine = rt.KDTree(len(tris), tris, len(verts), verts, nthreads=threads).arrays()
+        assert mine["depth"] == theirs["depth"]
+        for k in ("left", "right"):
+            assert np.array_equal(mine[k], theirs[k])
+        for k in ("center", "extent"):
+            assert np.array_equal(bits(mine[k]), bits(theirs[k]))
+        leaves = (mine["left"] < 0) & (mine["right"] < 0)
+        assert np.array_equal(mine["count"][leaves], theirs["count"][leaves])
+        assert np.array_equal(np.concatenate([mine["leaf_idx"][f:f + c] for f, c in zip(mine["first"][leaves], mine["count"][leaves])]),
+                              np.concatenate([theirs["leaf_idx"][f:f + c] for f, c in zip(theirs["first"][leaves], theirs["count"][leaves])]))
+
+
 def test_builder_rejects_bad_input_and_honours_node_guard():
     import raytracer_amd as rt
     from raytracer_amd import _capi, scenes
