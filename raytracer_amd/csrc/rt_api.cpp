@@ -6,6 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <memory>
+#include <chrono>
+#include <thread>
 #include <utility>
 #include <cmath>
 #include <cstdarg>
@@ -192,6 +195,26 @@ void grid_for(const rt_ctx* c, unsigned& gx, unsigned& gy)
     gx = (c->width + RT_TILE - 1) / RT_TILE;
     unsigned bands = (c->height + RT_TILE - 1) / RT_TILE;
     gy = bands > c->band_index ? (bands - c->band_index + c->band_count - 1) / c->band_count : 0;
+}
+
+// Host threads for the set-up of a large mesh (leaf records, the eight node arrays): RT_HOST_THREADS, else up to eight.
+unsigned host_threads()
+{
+    if (const char* e = getenv("RT_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return (unsigned)(v > 64 ? 64 : v); }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw == 0 ? 1u : (hw > 8u ? 8u : hw);
+}
+
+// f(chunk, first, last) over [0, n) in up to `threads` chunks; small ranges stay on the calling thread.
+template <typename F>
+void in_chunks(size_t n, unsigned threads, F f)
+{
+    if (threads <= 1 || n < 65536) { f(0u, (size_t)0, n); return; }
+    std::vector<std::thread> helpers;
+    const size_t per = (n + threads - 1) / threads;
+    for (unsigned k = 0; k + 1 < threads; ++k) helpers.emplace_back([=] { f(k, std::min(n, k * per), std::min(n, (k + 1) * per)); });
+    f(threads - 1, std::min(n, (threads - 1) * per), n);
+    for (auto& h : helpers) h.join();
 }
 
 constexpr float kAutoMaxTieRel = 1.0f / 512.0f;
@@ -517,17 +540,20 @@ int rt_set_mesh(rt_ctx* c, const float* verts, uint32_t nverts, const uint32_t* 
     c->h_tri_mat.assign(tri_mat, tri_mat + ntris);
     c->tri_mat_max = 0; c->tri_mat_max_at = 0;
     for (uint32_t i = 0; i < ntris; ++i) if (tri_mat[i] > c->tri_mat_max) { c->tri_mat_max = tri_mat[i]; c->tri_mat_max_at = i; }
-    std::vector<float4> shade(3 * (size_t)ntris);
-    for (uint32_t t = 0; t < ntris; ++t) {
-        const float* n = normals9 + 9 * (size_t)t;
-        float mbits; memcpy(&mbits, &tri_mat[t], 4);
-        shade[3 * (size_t)t] = make_float4(n[0], n[1], n[2], n[3]);
-        shade[3 * (size_t)t + 1] = make_float4(n[4], n[5], n[6], n[7]);
-        shade[3 * (size_t)t + 2] = make_float4(n[8], mbits, 0.0f, 0.0f);
-    }
+    std::unique_ptr<float4[]> shade_mem(new float4[3 * (size_t)ntris]);
+    float4* const shade = shade_mem.get();
+    in_chunks(ntris, host_threads(), [&](unsigned, size_t t_first, size_t t_last) {
+        for (size_t t = t_first; t < t_last; ++t) {
+            const float* n = normals9 + 9 * t;
+            float mbits; memcpy(&mbits, &tri_mat[t], 4);
+            shade[3 * t] = make_float4(n[0], n[1], n[2], n[3]);
+            shade[3 * t + 1] = make_float4(n[4], n[5], n[6], n[7]);
+            shade[3 * t + 2] = make_float4(n[8], mbits, 0.0f, 0.0f);
+        }
+    });
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, c->d_trishade.resize(shade.size()));
-    HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade.data(), shade.size() * sizeof(float4), hipMemcpyHostToDevice));
+    HIP_TRY(c, c->d_trishade.resize(3 * (size_t)ntris));
+    HIP_TRY(c, hipMemcpy(c->d_trishade.ptr, shade, 3 * (size_t)ntris * sizeof(float4), hipMemcpyHostToDevice));
     c->n_tris = ntris; c->n_verts = nverts;
     c->n_nodes = 0; c->n_refs = 0; c->d_nodes.release(); c->d_leafrecs.release();     // a new mesh invalidates the tree
     c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;
@@ -562,28 +588,48 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
         if (kd->left[n] >= 0) subtree[k] += subtree[new_index[(uint32_t)kd->left[n]]];
         if (kd->right[n] >= 0) subtree[k] += subtree[new_index[(uint32_t)kd->right[n]]];
     }
+    const unsigned threads = host_threads();
+    const bool times = getenv("RT_KD_TIMES") != nullptr;        // prints where the upload's time goes
+    const auto t_start = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (times) fprintf(stderr, "rt_set_kdtree: %s at %.3f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count());
+    };
     size_t n_refs = 0;
+    std::vector<uint32_t> ref_at(M, 0u);                 // per preorder position: the number of leaf references before it
     for (uint32_t k = 0; k < M; ++k) {
         uint32_t n = order[k];
+        ref_at[k] = (uint32_t)n_refs;
         if (kd->left[n] < 0 && kd->right[n] < 0) {
             if (kd->count[n] < 0 || kd->first[n] < 0 || (uint64_t)kd->first[n] + (uint64_t)kd->count[n] > kd->n_leaf_idx)
                 return fail(c, RT_E_ARG, "rt_set_kdtree: leaf %u range [%d, +%d) outside leaf_idx", n, kd->first[n], kd->count[n]);
             n_refs += (size_t)kd->count[n];
+            if (n_refs >= 0x7FFFFFFFull / 3) break;
         }
     }
     if (n_refs >= 0x7FFFFFFFull / 3) return fail(c, RT_E_LIMIT, "rt_set_kdtree: %zu leaf references exceed the index space", n_refs);
 
     // Leaf records in the reference's visit order (preorder, left first); a leaf's first record by original node id.
-    std::vector<float4> recs(3 * n_refs);
+    lap("preorder and leaf ranges");
+    // (memory the threads below touch first: a vector would fill it with zeros on this thread)
+    struct Records {
+        std::unique_ptr<float4[]> mem; size_t n = 0;
+        explicit Records(size_t count) : mem(count ? new float4[count] : nullptr), n(count) {}
+        float4& operator[](size_t i) { return mem[i]; }
+        bool empty() const { return n == 0; }
+        size_t size() const { return n; }
+        const float4* data() const { return mem.get(); }
+    } recs(3 * n_refs);
     std::vector<int32_t> leaf_first_of(N, RT_LEAF_INTERIOR);
-    size_t next_ref = 0;
-    for (uint32_t k = 0; k < M; ++k) {
+    std::vector<int64_t> bad_tri(threads, -1), bad_leaf(threads, -1);      // per chunk: the first triangle index out of range
+    in_chunks(M, threads, [&](unsigned chunk, size_t k_first, size_t k_last) {
+    for (uint32_t k = (uint32_t)k_first; k < (uint32_t)k_last; ++k) {
         uint32_t n = order[k];
         if (kd->left[n] >= 0 || kd->right[n] >= 0) continue;
+        size_t next_ref = ref_at[k];
         leaf_first_of[n] = kd->count[n] > 0 ? (int32_t)next_ref : RT_LEAF_EMPTY;
         for (int32_t i = 0; i < kd->count[n]; ++i) {
             int32_t tri = kd->leaf_idx[kd->first[n] + i];
-            if (tri < 0 || (uint32_t)tri >= c->n_tris) return fail(c, RT_E_ARG, "rt_set_kdtree: triangle index %d out of range in leaf %u", tri, n);
+            if (tri < 0 || (uint32_t)tri >= c->n_tris) { if (bad_leaf[chunk] < 0) { bad_tri[chunk] = tri; bad_leaf[chunk] = n; } return; }
             const uint32_t* ix = &c->h_tris[3 * (size_t)tri];
             const float* v0 = &c->h_verts[3 * (size_t)ix[0]];
             const float* v1 = &c->h_verts[3 * (size_t)ix[1]];
@@ -600,12 +646,18 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             ++next_ref;
         }
     }
+    });
+    for (unsigned k = 0; k < threads; ++k)
+        if (bad_leaf[k] >= 0) return fail(c, RT_E_ARG, "rt_set_kdtree: triangle index %d out of range in leaf %u", (int)bad_tri[k], (unsigned)bad_leaf[k]);
+    lap("leaf records");
 
     // Per two-child node: the axis along which its children are separated and which child is the low one; whether the
     // tree is a KD tree (each two-child node's children are its own box cut in two along that axis).
     std::vector<uint8_t> sep_axis(N, 3), low_is_left(N, 1);
+    std::vector<uint8_t> chunk_partition(threads, 1);
+    in_chunks(M, threads, [&](unsigned chunk, size_t k_first, size_t k_last) {
     bool partition = true;
-    for (uint32_t k = 0; k < M; ++k) {
+    for (uint32_t k = (uint32_t)k_first; k < (uint32_t)k_last; ++k) {
         const uint32_t n = order[k];
         const int32_t l = kd->left[n], r = kd->right[n];
         if (l < 0 || r < 0) continue;
@@ -632,6 +684,11 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             partition = near(clo[a] - elo[a], lo) && near(chi[a] + ehi[a], hi) && near(clo[a] + elo[a], chi[a] - ehi[a]);
         }
     }
+    chunk_partition[chunk] = partition ? 1 : 0;
+    });
+    bool partition = true;
+    for (unsigned k = 0; k < threads; ++k) partition = partition && chunk_partition[k] != 0;
+    lap("child order per node");
 
     DeviceGuard g(c->device);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -645,66 +702,96 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     // preorder that walks, at every two-child node, the child on the side a ray of that pattern comes from first.  Array 0
     // is always left-first: it is the reference's own order (RT_ORDER_REFERENCE, the column pre-pass and the cooperative
     // walk use it), and for a tree of the reference builder the left child is the low one, which is what pattern 0 wants.
-    std::vector<float4> nodes(2 * (size_t)M);
-    std::vector<uint32_t> walk; walk.reserve(M);
+    // (the arrays are independent of each other: up to `threads` of them are made at a time, each by a thread of its own)
     std::vector<uint32_t> subtree_of(N, 0);
     for (uint32_t k = 0; k < M; ++k) subtree_of[order[k]] = subtree[k];
-    for (uint32_t o = 0; o < 8; ++o) {
-        walk.clear(); stack.clear(); stack.push_back(0);
-        uint32_t k = 0;
-        while (!stack.empty()) {
-            const uint32_t n = stack.back(); stack.pop_back();
-            const int32_t l = kd->left[n], r = kd->right[n];
-            const uint32_t skip = k + subtree_of[n];
-            const int32_t leaf_first = leaf_first_of[n];
-            float skipf, leaff; memcpy(&skipf, &skip, 4); memcpy(&leaff, &leaf_first, 4);
-            nodes[2 * (size_t)k] = make_float4(kd->center[3 * (size_t)n], kd->center[3 * (size_t)n + 1], kd->center[3 * (size_t)n + 2], skipf);
-            nodes[2 * (size_t)k + 1] = make_float4(kd->extent[3 * (size_t)n], kd->extent[3 * (size_t)n + 1], kd->extent[3 * (size_t)n + 2], leaff);
-            ++k;
-            if (l >= 0 && r >= 0) {
-                bool left_first = true;
-                if (o != 0 && sep_axis[n] != 3) {
-                    const bool from_high = (o >> sep_axis[n]) & 1u;            // the ray travels towards lower coordinates
-                    left_first = from_high ? !low_is_left[n] : (bool)low_is_left[n];
-                }
-                if (left_first) { stack.push_back((uint32_t)r); stack.push_back((uint32_t)l); }
-                else            { stack.push_back((uint32_t)l); stack.push_back((uint32_t)r); }
-            } else if (l >= 0) stack.push_back((uint32_t)l);
-            else if (r >= 0) stack.push_back((uint32_t)r);
-        }
-        HIP_TRY(c, hipMemcpy(c->d_nodes.ptr + (size_t)o * 2 * M, nodes.data(), nodes.size() * sizeof(float4), hipMemcpyHostToDevice));
+    const unsigned at_a_time = threads < 8u ? threads : 8u;
+    std::vector<std::unique_ptr<float4[]>> arrays(at_a_time);
+    for (uint32_t o_first = 0; o_first < 8; o_first += at_a_time) {
+        auto make_array = [&](uint32_t o) {
+            if (!arrays[o - o_first]) arrays[o - o_first].reset(new float4[2 * (size_t)M]);
+            float4* const nodes = arrays[o - o_first].get();
+            std::vector<uint32_t> todo; todo.push_back(0);
+            uint32_t k = 0;
+            while (!todo.empty()) {
+                const uint32_t n = todo.back(); todo.pop_back();
+                const int32_t l = kd->left[n], r = kd->right[n];
+                const uint32_t skip = k + subtree_of[n];
+                const int32_t leaf_first = leaf_first_of[n];
+                float skipf, leaff; memcpy(&skipf, &skip, 4); memcpy(&leaff, &leaf_first, 4);
+                nodes[2 * (size_t)k] = make_float4(kd->center[3 * (size_t)n], kd->center[3 * (size_t)n + 1], kd->center[3 * (size_t)n + 2], skipf);
+                nodes[2 * (size_t)k + 1] = make_float4(kd->extent[3 * (size_t)n], kd->extent[3 * (size_t)n + 1], kd->extent[3 * (size_t)n + 2], leaff);
+                ++k;
+                if (l >= 0 && r >= 0) {
+                    bool left_first = true;
+                    if (o != 0 && sep_axis[n] != 3) {
+                        const bool from_high = (o >> sep_axis[n]) & 1u;            // the ray travels towards lower coordinates
+                        left_first = from_high ? !low_is_left[n] : (bool)low_is_left[n];
+                    }
+                    if (left_first) { todo.push_back((uint32_t)r); todo.push_back((uint32_t)l); }
+                    else            { todo.push_back((uint32_t)l); todo.push_back((uint32_t)r); }
+                } else if (l >= 0) todo.push_back((uint32_t)l);
+                else if (r >= 0) todo.push_back((uint32_t)r);
+            }
+        };
+        const uint32_t o_last = o_first + at_a_time < 8u ? o_first + at_a_time : 8u;
+        std::vector<std::thread> helpers;
+        if (M >= 65536u) for (uint32_t o = o_first + 1; o < o_last; ++o) helpers.emplace_back(make_array, o);
+        else for (uint32_t o = o_first + 1; o < o_last; ++o) make_array(o);
+        make_array(o_first);
+        for (auto& h : helpers) h.join();
+        for (uint32_t o = o_first; o < o_last; ++o)
+            HIP_TRY(c, hipMemcpy(c->d_nodes.ptr + (size_t)o * 2 * M, arrays[o - o_first].get(), 2 * (size_t)M * sizeof(float4), hipMemcpyHostToDevice));
     }
+    arrays.clear(); arrays.shrink_to_fit();
+    lap("eight node arrays made and copied");
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
+    lap("leaf records copied");
     HIP_TRY(c, c->d_reached.resize(M));
     HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
     {
         std::vector<uint32_t> rec_leaf(recs.size() / 3 + 1, 0u);
-        for (size_t r = 0; r < recs.size() / 3; ++r) memcpy(&rec_leaf[r], &recs[3 * r + 2].z, 4);
+        in_chunks(recs.size() / 3, threads, [&](unsigned, size_t r_first, size_t r_last) {
+            for (size_t r = r_first; r < r_last; ++r) memcpy(&rec_leaf[r], &recs[3 * r + 2].z, 4);
+        });
         HIP_TRY(c, c->d_rec_leaf.resize(rec_leaf.size()));
         HIP_TRY(c, hipMemcpy(c->d_rec_leaf.ptr, rec_leaf.data(), rec_leaf.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     {
         // the near-tie distance of the front-to-back walk (RtParams::tie_*)
+        // (maxima over the nodes and over the triangles, found per chunk and combined: a maximum does not depend on the order)
+        struct Bounds { double reach[3] = {0.0, 0.0, 0.0}, mag[3] = {0.0, 0.0, 0.0}, k_max = 0.0, e_max = 0.0; bool bounded = true; };
+        std::vector<Bounds> part(2 * (size_t)threads);
+        in_chunks(N, threads, [&](unsigned chunk, size_t n_first, size_t n_last) {
+            Bounds& b = part[chunk];
+            for (size_t n = n_first; n < n_last; ++n)
+                for (int a = 0; a < 3; ++a) {
+                    const double ce = kd->center[3 * n + a], ex = std::fabs((double)kd->extent[3 * n + a]);
+                    b.reach[a] = std::max(b.reach[a], std::fabs(ce - (double)kd->center[a]) + ex);
+                    b.mag[a] = std::max(b.mag[a], std::fabs(ce) + ex);
+                    if (!(std::fabs(ce) + ex <= 0x1p60)) b.bounded = false;
+                }
+        });
+        in_chunks(c->n_tris, threads, [&](unsigned chunk, size_t t_first, size_t t_last) {
+            Bounds& b = part[threads + chunk];
+            for (size_t t = t_first; t < t_last; ++t) {
+                const uint32_t* ix = &c->h_tris[3 * t];
+                const float* v0 = &c->h_verts[3 * (size_t)ix[0]]; const float* v1 = &c->h_verts[3 * (size_t)ix[1]]; const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
+                double n1 = 0.0, n2 = 0.0;
+                for (int a = 0; a < 3; ++a) {
+                    const double d1 = std::fabs((double)v1[a] - v0[a]), d2 = std::fabs((double)v2[a] - v0[a]);
+                    n1 += d1; n2 += d2; b.e_max = std::max(b.e_max, std::max(d1, d2));
+                }
+                b.k_max = std::max(b.k_max, n1 * n2);
+                if (!(n1 * n2 <= 0x1p56)) b.bounded = false;     // (also a NaN among the vertices)
+            }
+        });
         double reach[3] = {0.0, 0.0, 0.0}, mag[3] = {0.0, 0.0, 0.0};
-        bool bounded = true;                               // no box beyond 2^60, no triangle with |e1|_1 |e2|_1 beyond 2^56, no NaN: RtParams::slab_plain
-        for (uint32_t n = 0; n < N; ++n)
-            for (int a = 0; a < 3; ++a) {
-                const double ce = kd->center[3 * (size_t)n + a], ex = std::fabs((double)kd->extent[3 * (size_t)n + a]);
-                reach[a] = std::max(reach[a], std::fabs(ce - (double)kd->center[a]) + ex);
-                mag[a] = std::max(mag[a], std::fabs(ce) + ex);
-                if (!(std::fabs(ce) + ex <= 0x1p60)) bounded = false;
-            }
         double k_max = 0.0, e_max = 0.0;                   // max |e1|_1 |e2|_1 and the longest edge component over the triangles
-        for (uint32_t t = 0; t < c->n_tris; ++t) {
-            const uint32_t* ix = &c->h_tris[3 * (size_t)t];
-            const float* v0 = &c->h_verts[3 * (size_t)ix[0]]; const float* v1 = &c->h_verts[3 * (size_t)ix[1]]; const float* v2 = &c->h_verts[3 * (size_t)ix[2]];
-            double n1 = 0.0, n2 = 0.0;
-            for (int a = 0; a < 3; ++a) {
-                const double d1 = std::fabs((double)v1[a] - v0[a]), d2 = std::fabs((double)v2[a] - v0[a]);
-                n1 += d1; n2 += d2; e_max = std::max(e_max, std::max(d1, d2));
-            }
-            k_max = std::max(k_max, n1 * n2);
-            if (!(n1 * n2 <= 0x1p56)) bounded = false;     // (also a NaN among the vertices)
+        bool bounded = true;                               // no box beyond 2^60, no triangle with |e1|_1 |e2|_1 beyond 2^56, no NaN: RtParams::slab_plain
+        for (const Bounds& b : part) {
+            for (int a = 0; a < 3; ++a) { reach[a] = std::max(reach[a], b.reach[a]); mag[a] = std::max(mag[a], b.mag[a]); }
+            k_max = std::max(k_max, b.k_max); e_max = std::max(e_max, b.e_max); bounded = bounded && b.bounded;
         }
         c->slab_plain = bounded;
         c->mesh_mag = std::max(mag[0], std::max(mag[1], mag[2])); c->mesh_emax = e_max;
@@ -753,6 +840,7 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
             }
         }
     }
+    lap("bounds and leaf-list check");
     c->n_nodes = M; c->n_refs = (uint32_t)n_refs; c->kd_partition = partition; c->kd_listing = listing; c->column_cache = false; c->first_hits_valid = false; c->units_valid = false;
     return RT_OK;
 }
