@@ -104,6 +104,7 @@ struct rt_ctx {
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
     uint32_t last_grid_waves = 0;
+    unsigned resume_lanes = 1;              // parked paths per wave of a resume launch (RT_RESUME_LANES=<1..64, a power of two> overrides)
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
     std::vector<float4> h_materials;     // packed materials as uploaded
     // page-locked staging for the per-frame scene tables: a ring, so an upload never waits for the frame before it
@@ -385,6 +386,7 @@ rt_ctx* rt_create(int device_id)
     }
     c->n_cus = prop.multiProcessorCount;
     (void)rt_static_setup(device_id);      // set-up of rt_render_spheres_noalloc on this device (it reports a failure itself when called)
+    if (const char* e = getenv("RT_RESUME_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->resume_lanes = (unsigned)v; }
     if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) { c->park_min_nodes = (uint32_t)v; c->park_min_forced = true; } }
     return c;
 }
@@ -1036,7 +1038,13 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
         LAUNCH_TRY(c, rt_launch_parked_rays(&q, c->stats ? 1 : 0, c->stream));
         q.resume = last ? 2u : 1u;
         const unsigned slots = parked < RT_PARK_SLOTS ? parked : RT_PARK_SLOTS;
-        LAUNCH_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (slots + rt_trace_block(mode) - 1u) / rt_trace_block(mode), c->stream));
+        // few paths per wave (see RtParams::resume_lanes), as far as the per-wave counter slots allow
+        const unsigned waves_per_block = rt_trace_block(mode) / 64u, max_waves = (unsigned)(c->d_counters.count / 4);
+        unsigned lanes = c->resume_lanes;
+        while (lanes < 64u && (slots + lanes - 1u) / lanes > max_waves / waves_per_block * waves_per_block) lanes *= 2u;
+        q.resume_lanes = lanes;
+        const unsigned waves = (slots + lanes - 1u) / lanes;
+        LAUNCH_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (waves + waves_per_block - 1u) / waves_per_block, c->stream));
         if (last) break;
         cur = 1 - cur;
         HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));

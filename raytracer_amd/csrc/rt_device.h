@@ -224,5 +224,6 @@ struct RtParams {
     int32_t   ray_slot;                      // which rays the reach / test kernels serve: -1 = the column rays, else a family of parked rays
     uint32_t  resume;                        // trace kernel: 0 = draw units; 1 = continue the paths of the resume list (may park again);
                                              // 2 = the same, but rays the tree cannot prune are walked by their wave
+    uint32_t  resume_lanes;                  // ... by the first resume_lanes lanes of each wave, one path each (path w * resume_lanes + lane)
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

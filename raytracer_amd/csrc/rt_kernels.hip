@@ -1013,8 +1013,15 @@ __global__ __launch_bounds__(1024) void rt_column_scan_kernel(RtParams p, uint32
     const uint32_t tid = threadIdx.x;
     const uint32_t per = (n_blocks + 1023u) / 1024u;
     const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    // (eight reads in flight per thread: one after the other, a thread's few dozen reads are a chain of as many memory latencies)
     uint32_t sum = 0;
-    for (uint32_t i = lo; i < hi; ++i) sum += p.column_block[i];
+    for (uint32_t i = lo; i < hi; i += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = i + k < hi ? p.column_block[i + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) sum += v[k];
+    }
     part[tid] = sum;
     __syncthreads();
     for (uint32_t off = 1; off < 1024u; off <<= 1) {               // Hillis-Steele inclusive scan
@@ -1024,7 +1031,13 @@ __global__ __launch_bounds__(1024) void rt_column_scan_kernel(RtParams p, uint32
         __syncthreads();
     }
     uint32_t run = tid ? part[tid - 1] : 0u;
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = p.column_block[i]; p.column_block[i] = run; run += c; }
+    for (uint32_t i = lo; i < hi; i += 8u) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) v[k] = i + k < hi ? p.column_block[i + k] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) if (i + k < hi) { p.column_block[i + k] = run; run += v[k]; }
+    }
     if (tid == 1023u) *p.column_count = part[1023];
 }
 
@@ -1137,27 +1150,47 @@ __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
     }
 }
 
-// Exclusive prefix maximum of the per-block maxima, in place, by one workgroup.
+// Exclusive prefix maximum of the per-block maxima, in place, by one workgroup.  Each of its sixteen waves owns a run of the
+// array and goes through it 64 consecutive values at a time, four reads in flight (a contiguous range per THREAD would make
+// every read of a wave touch 64 cache lines: with a tree of 14 M nodes this kernel then took longer than the two passes over the
+// nodes on either side of it).
 __global__ __launch_bounds__(1024) void rt_column_reach_scan_kernel(RtParams p, uint32_t n_blocks)
 {
-    __shared__ uint32_t part[1024];
+    __shared__ uint32_t part[16];
     F3 O, D; uint32_t count;
     if (!reach_ray(p, O, D, count)) return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t per = (n_blocks + 1023u) / 1024u;
-    const uint32_t lo = tid * per, hi = (lo + per < n_blocks) ? lo + per : n_blocks;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t seg = (((n_blocks + 15u) / 16u) + 63u) & ~63u;
+    const uint32_t lo = wv * seg < n_blocks ? wv * seg : n_blocks, hi = lo + seg < n_blocks ? lo + seg : n_blocks;
+    uint32_t* const blk = p.column_block;
     uint32_t mx = 0;
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.column_block[i]; mx = mx > v ? mx : v; }
-    part[tid] = mx;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024u; off <<= 1) {
-        const uint32_t v = tid >= off ? part[tid - off] : 0u;
-        __syncthreads();
-        part[tid] = part[tid] > v ? part[tid] : v;
-        __syncthreads();
+    for (uint32_t base = lo; base < hi; base += 256u) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = base + 64u * k + lane; v[k] = i < hi ? blk[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) mx = mx > v[k] ? mx : v[k];
     }
-    uint32_t run = tid ? part[tid - 1] : 0u;
-    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.column_block[i]; p.column_block[i] = run; run = run > v ? run : v; }
+    mx = (uint32_t)__shfl((int)wave_inclusive_max(mx, lane), 63);
+    if (lane == 0u) part[wv] = mx;
+    __syncthreads();
+    uint32_t run = 0;                                               // maximum over everything before this wave's run
+    for (uint32_t w = 0; w < wv; ++w) run = run > part[w] ? run : part[w];
+    for (uint32_t base = lo; base < hi; base += 256u) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) { const uint32_t i = base + 64u * k + lane; v[k] = i < hi ? blk[i] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const uint32_t i = base + 64u * k + lane;
+            const uint32_t incl = wave_inclusive_max(v[k], lane);
+            uint32_t excl = __shfl_up(incl, 1);
+            if (lane == 0u) excl = 0u;
+            if (i < hi) blk[i] = run > excl ? run : excl;
+            const uint32_t all = (uint32_t)__shfl((int)incl, 63);
+            run = run > all ? run : all;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, int stats)
@@ -1817,10 +1850,12 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     uint32_t resume_slot = 0;
     if (p.resume) {
         heads_empty = RT_WORK_HEADS;                        // no units: only the parked paths are finished
+        // (few paths per wave, RtParams::resume_lanes: what is left of them is a chain of walks each, and a wave that holds no more
+        // than RT_COOP_LANES walks lends all its lanes to one walk at a time)
         const uint32_t n_parked = *p.resume_count < RT_PARK_SLOTS ? *p.resume_count : RT_PARK_SLOTS;
-        if (wave * 64u >= n_parked) return;
-        resume_slot = wave * 64u + lane;
-        if (resume_slot < n_parked) {
+        if (wave * p.resume_lanes >= n_parked) return;
+        resume_slot = wave * p.resume_lanes + lane;
+        if (lane < p.resume_lanes && resume_slot < n_parked) {
             const float4* q = p.resume_paths + RT_PARK_WORDS * resume_slot;
             const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4];
             static_assert(RT_PARK_WORDS == 5, "a parked path is five float4");
