@@ -243,10 +243,11 @@ int rt_set_stats(rt_ctx*, int on);
 int rt_read_counters(rt_ctx*, rt_counters* out);
 int rt_reset_counters(rt_ctx*);
 /* Diagnostics.  rt_set_stats(ctx, flags): bit 0 = count nodes / triangles (the counting kernels), bit 1 = record, per wave
-   of the trace launch, 6 values: the 100 MHz device clock at its start and end, the main-loop iterations it made and, in
+   of the trace launch, 8 values: the 100 MHz device clock at its start and end, the main-loop iterations it made and, in
    tree scenes, the trips of its walk loop (one read at each walking lane's cursor per trip), the sum over those trips of
-   the lanes that were walking (counting kernels only; / (64 x trips) = how full the trips were) and the clock ticks spent
-   inside the walk loop.  out holds 6 * max_waves values; the number of waves written is returned through *n_waves. */
+   the lanes that were walking (counting kernels only; / (64 x trips) = how full the trips were), the clock ticks spent
+   inside the walk loop, those spent without a path of its own, waiting for paths of the workgroup's other waves, and those
+   spent in the shading block.  out holds 8 * max_waves values; the number of waves written is returned through *n_waves. */
 int rt_read_wave_clock(rt_ctx*, uint64_t* out, uint32_t max_waves, uint32_t* n_waves);
 int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
 int rt_reset_kernel_time(rt_ctx*);

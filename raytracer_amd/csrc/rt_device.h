@@ -73,7 +73,7 @@
 #define RT_POOL_SLOTS 16           // paths the pool holds while they change waves
 #define RT_POOL_WORDS 38           // 32-bit words of one path's state
 #define RT_LONG_WALK 48            // node + triangle steps after which a tree walk raises its wave's issue priority
-#define RT_WAVE_CLOCK_WORDS 6
+#define RT_WAVE_CLOCK_WORDS 8
 #define RT_WORK_HEADS 8            // ticket counters units are pulled from on tree scenes (one per XCD under round-robin dispatch), each on a 128-byte line of its own
 #define RT_HEAD_STRIDE 32          // words between heads
 #define RT_INLINE_SPHERES 32       // spheres carried in the kernel arguments (scalar loads); more go through HBM
@@ -164,7 +164,7 @@ struct RtParams {
     const uint32_t* unit_entry;
     uint32_t* unit_entry_out; uint32_t entry_ordered;
     unsigned long long* counters;           // 4 per wave of the persistent grid: rays, nodes, tris, sphere tests
-    unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: start, end (100 MHz clock), main-loop iterations, walk-loop
+    unsigned long long* wave_clock;         // RT_WAVE_CLOCK_WORDS per wave: [6] ticks spent waiting for paths of other waves, [7] ticks in the shading block; start, end (100 MHz clock), main-loop iterations, walk-loop
                                             // trips, sum over trips of the walking lanes (counting kernels), ticks inside the walk loop
     unsigned long long* column_stats;       // 8: nodes / triangles the reference's walk spends on the column rays; rays walked again in the
                                             // reference's order because of a near tie; primary rays answered from first_hits; [4] the

@@ -1727,7 +1727,7 @@ __device__ __forceinline__ void sphere_body(const RtParams& p)
     if (clocked && lane == 0) {
         unsigned long long* wc = p.wave_clock + RT_WAVE_CLOCK_WORDS * (size_t)wave;
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
-        wc[3] = 0; wc[4] = 0; wc[5] = 0;
+        wc[3] = 0; wc[4] = 0; wc[5] = 0; wc[6] = 0; wc[7] = 0;
     }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {
@@ -1795,7 +1795,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     bool waiting = false;                                   // wave-uniform: this wave is counted in pool.hungry, not in pool.busy
     uint32_t head = blockIdx.x % RT_WORK_HEADS, heads_empty = 0;        // wave-uniform: the ticket head drawn from, heads found empty
     uint32_t n_rays = 0, n_nodes = 0, n_tris = 0, n_reused = 0;
-    unsigned long long clock_start = 0, trips = 0, lane_trips = 0, walk_ticks = 0; uint32_t n_iterations = 0;
+    unsigned long long clock_start = 0, trips = 0, lane_trips = 0, walk_ticks = 0, wait_ticks = 0, shade_ticks = 0; uint32_t n_iterations = 0;
     const bool clocked = p.wave_clock != nullptr && !p.resume;
     if (clocked) clock_start = __builtin_amdgcn_s_memrealtime();
 
@@ -1900,6 +1900,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     waiting = true;
                 }
                 bool leave = false;
+                const unsigned long long wait_start = clocked ? __builtin_amdgcn_s_memrealtime() : 0ull;
                 for (;;) {
                     if (lds_peek(&pool.count) != 0u) {
                         lds_lock(&pool.lock, lane);
@@ -1917,6 +1918,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         if (leave) break;
                     } else __builtin_amdgcn_s_sleep(8);
                 }
+                if (clocked) wait_ticks += __builtin_amdgcn_s_memrealtime() - wait_start;
                 if (leave) break;
             } else if (n_live > (uint32_t)RT_KEEP) {
                 const uint32_t wanted = lds_peek(&pool.hungry) * (uint32_t)RT_ADOPT, have = lds_peek(&pool.count);
@@ -2175,6 +2177,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         }
 
         // ---- the lanes whose ray is traced: the rest of the bounce (Renderer.cpp:160-226)
+        const unsigned long long shade_start = clocked ? __builtin_amdgcn_s_memrealtime() : 0ull;
         if (phase == PH_SHADE) resolve_detected(th);
         if (phase == PH_SHADE && p.first_hit_mode == 1u) {
             // only the primary ray's mesh hit is wanted: kept for the launches that follow
@@ -2198,6 +2201,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                 path_steps = 0;
             }
         }
+        if (clocked) shade_ticks += __builtin_amdgcn_s_memrealtime() - shade_start;
     }
     __builtin_amdgcn_s_setprio(0);
 
@@ -2206,6 +2210,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         wc[0] = clock_start; wc[1] = __builtin_amdgcn_s_memrealtime(); wc[2] = n_iterations;
         wc[3] = trips; wc[4] = lane_trips;                  // lane balance = lane_trips / (64 trips), counting kernels only
         wc[5] = walk_ticks;                                 // time inside the walk slices
+        wc[6] = wait_ticks; wc[7] = shade_ticks;            // ... waiting for paths from other waves, in the shading block
     }
     // work counters: one slot group per wave, summed on the host when read
     if (p.counters) {

@@ -317,9 +317,10 @@ class Renderer:
         return c
 
     def read_wave_clock(self, max_waves=16384):
-        """(n, 6) uint64 per wave of the last trace launch made with set_stats(2 or 3): start, end (100 MHz ticks), main-loop
-        iterations, walk-loop trips, sum over trips of the walking lanes (set_stats(3) only), ticks inside the walk loop."""
-        out = np.zeros((max_waves, 6), np.uint64)
+        """(n, 8) uint64 per wave of the last trace launch made with set_stats(2 or 3): start, end (100 MHz ticks), main-loop
+        iterations, walk-loop trips, sum over trips of the walking lanes (set_stats(3) only), ticks inside the walk loop, ticks
+        spent waiting for paths of other waves, ticks in the shading block."""
+        out = np.zeros((max_waves, 8), np.uint64)
         n = C.c_uint32()
         check(self._h, self._L.rt_read_wave_clock(self._h, ptr(out), max_waves, C.byref(n)), "rt_read_wave_clock")
         return out[:n.value]

@@ -43,6 +43,10 @@ if wc[:, 3].sum() > 0:
     trips, lanes, walk = wc[:, 3], wc[:, 4], wc[:, 5] * 0.01
     print("  walk loop: %.0f trips over all waves, %.2f us per trip, %.3f of the waves' time" % (trips.sum(), walk.sum() / trips.sum(), walk.sum() / dur.sum()))
     print("  trips per iteration  :", q(trips / np.maximum(it, 1)))
+    wait, shade = wc[:, 6] * 0.01, wc[:, 7] * 0.01
+    print("  of the waves' time: %.3f waiting for paths of other waves, %.3f in the shading block, %.3f elsewhere (refill, ray set-up, hand-over)" %
+          (wait.sum() / dur.sum(), shade.sum() / dur.sum(), 1.0 - (walk.sum() + wait.sum() + shade.sum()) / dur.sum()))
+    print("  waiting us per wave  :", q(wait))
     if lanes.sum() > 0:
         print("  walking lanes per trip: %.1f of 64 over the frame" % (lanes.sum() / trips.sum()))
     print("  the 12 last waves (duration us, iterations, trips, us per trip, us outside the walk loop):",
