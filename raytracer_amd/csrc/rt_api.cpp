@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "../../include/rt_mi355x.h"
@@ -213,7 +214,11 @@ void in_chunks(size_t n, unsigned threads, F f)
     if (threads <= 1 || n < 65536) { f(0u, (size_t)0, n); return; }
     std::vector<std::thread> helpers;
     const size_t per = (n + threads - 1) / threads;
-    for (unsigned k = 0; k + 1 < threads; ++k) helpers.emplace_back([=] { f(k, std::min(n, k * per), std::min(n, (k + 1) * per)); });
+    for (unsigned k = 0; k + 1 < threads; ++k) {
+        const size_t first = std::min(n, k * per), last = std::min(n, (k + 1) * per);
+        try { helpers.emplace_back([=] { f(k, first, last); }); }
+        catch (const std::system_error&) { f(k, first, last); }         // no thread to be had: the chunk is done here
+    }
     f(threads - 1, std::min(n, (threads - 1) * per), n);
     for (auto& h : helpers) h.join();
 }
@@ -738,8 +743,11 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
         };
         const uint32_t o_last = o_first + at_a_time < 8u ? o_first + at_a_time : 8u;
         std::vector<std::thread> helpers;
-        if (M >= 65536u) for (uint32_t o = o_first + 1; o < o_last; ++o) helpers.emplace_back(make_array, o);
-        else for (uint32_t o = o_first + 1; o < o_last; ++o) make_array(o);
+        for (uint32_t o = o_first + 1; o < o_last; ++o) {
+            if (M < 65536u) { make_array(o); continue; }
+            try { helpers.emplace_back(make_array, o); }
+            catch (const std::system_error&) { make_array(o); }
+        }
         make_array(o_first);
         for (auto& h : helpers) h.join();
         for (uint32_t o = o_first; o < o_last; ++o)

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -131,7 +132,11 @@ void chunked(int n, int threads, F f)
     if (threads <= 1) { f(0, 0, n); return; }
     std::vector<std::thread> helpers;
     const int per = (n + threads - 1) / threads;
-    for (int c = 0; c + 1 < threads; ++c) helpers.emplace_back([=] { f(c, std::min(n, c * per), std::min(n, (c + 1) * per)); });
+    for (int c = 0; c + 1 < threads; ++c) {
+        const int first = std::min(n, c * per), last = std::min(n, (c + 1) * per);
+        try { helpers.emplace_back([=] { f(c, first, last); }); }
+        catch (const std::system_error&) { f(c, first, last); }         // no thread to be had: the chunk is done here
+    }
     f(threads - 1, std::min(n, (threads - 1) * per), n);
     for (auto& h : helpers) h.join();
 }
@@ -495,7 +500,10 @@ rt_host_kd* rt_host_kd_build(const float* verts, uint32_t nverts, const uint32_t
     }
     lap("wide nodes split");
     std::vector<std::thread> pool;
-    for (int i = 1; i < nthreads; ++i) pool.emplace_back([&b] { b.worker(); });
+    for (int i = 1; i < nthreads; ++i) {
+        try { pool.emplace_back([&b] { b.worker(); }); }
+        catch (const std::system_error&) { break; }                     // fewer workers, the same tree
+    }
     b.worker();
     for (auto& th : pool) th.join();
     if (b.overflow) return nullptr;
@@ -546,7 +554,10 @@ rt_host_kd* rt_host_kd_build(const float* verts, uint32_t nverts, const uint32_t
         std::atomic<size_t> next{0};
         auto run = [&] { for (size_t i; (i = next.fetch_add(1)) < tasks.size();) emit_subtree(tasks[i], true); };
         std::vector<std::thread> helpers;
-        for (int i = 1; i < nthreads; ++i) helpers.emplace_back(run);
+        for (int i = 1; i < nthreads; ++i) {
+            try { helpers.emplace_back(run); }
+            catch (const std::system_error&) { break; }
+        }
         run();
         for (auto& h : helpers) h.join();
     }
