@@ -54,6 +54,13 @@ CONFIGS = {
 }
 
 
+KERNEL_TIMING_EVERY = 8
+KERNEL_TIME_SOURCE = ("HIP events on the launch stream around every %dth launch of the timed region, the first included (the two event "
+                      "records of a launch cost a 1080p sphere frame about 8 us: timing every launch slows what is being timed; a timed launch stands "
+                      "alone between its two markers and its time includes its own dispatch, while an untimed launch is set up behind the "
+                      "running one, so ms_per_step can come out slightly below kernel_avg_ms)" % KERNEL_TIMING_EVERY)
+
+
 def host_threads():
     """Threads for host-side work: this process's CPU share (a GPU box shows the whole machine's CPUs to os.cpu_count())."""
     try:
@@ -152,10 +159,11 @@ TRAFFIC_SOURCE = "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of a rocprofv3 
 def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, profiling=False):
     """Price the trace kernel of the timed launches (cnt / kt: their counters and event times) against its bound."""
     px = cfg["w"] * cfg["h"]
-    launches = max(kt.launches, 1)
-    avg_kernel_s = kt.total_ms / launches / 1e3
+    timed = max(kt.launches, 1)                                      # launches with HIP events around them (KERNEL_TIMING_EVERY)
+    avg_kernel_s = kt.total_ms / timed / 1e3
+    frames_per_launch = max(1, round(kt.frames / timed))             # 1, or 16 under --profile throughput
+    launches = max(1, round(len(frames) / frames_per_launch))        # all launches of the timed region
     rays_per_launch = cnt.rays / launches
-    frames_per_launch = max(1, round(len(frames) / launches))        # 1, or 16 under --profile throughput
     px = px * frames_per_launch                                      # pixel-frames per launch
     traffic = _traffic_from_profile(config_id, frames_per_launch)
     if cfg["mode"] == 1:
@@ -165,7 +173,8 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
                 "frac": achieved / PEAK_VALU_NOFMA_TFLOPS, "traffic": traffic, "traffic_source": TRAFFIC_SOURCE,
                 "hbm_algorithmic_GBs": px * BYTES_PER_PIXEL_FRAME / avg_kernel_s / 1e9,
                 "hbm_moved_GBs": (traffic / avg_kernel_s / 1e9) if traffic else None,
-                "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
+                "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": launches,
+                "launches_timed": int(kt.launches), "kernel_time_source": KERNEL_TIME_SOURCE,
                 "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
                 "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path; accum and dirs are float4 "
                         "(32 B + 16 B per pixel against the 24 B + 0 B of the 40 B/pixel model), hence traffic about twice the algorithmic bytes"}
@@ -217,8 +226,9 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
             "frac_hbm_moved": (traffic / avg_kernel_s / 1e9 / PEAK_HBM_GBS) if traffic else None,
             "algorithmic_bytes_per_launch": bytes_,
             "kernel": "rt_trace_kernel<%s, %s>" % ("mesh" if cfg["mode"] == 0 else "spheres+mesh", order_used),
-            "kernel_avg_ms": avg_kernel_s * 1e3, "launches": int(kt.launches),
-            "prepass_avg_ms": kt.prepass_total_ms / launches,
+            "kernel_avg_ms": avg_kernel_s * 1e3, "launches": launches,
+            "launches_timed": int(kt.launches), "kernel_time_source": KERNEL_TIME_SOURCE,
+            "prepass_avg_ms": kt.prepass_total_ms / timed,
             "nodes_per_ray": (own_nodes - skipped - spared_nodes) / max(rays_per_launch, 1),
             "tris_per_ray": (own_tris - spared_tris) / max(rays_per_launch, 1),
             "column_rays_reference_equivalent": {"nodes_per_frame": per_frame(c2.prepass_nodes), "tris_per_frame": per_frame(c2.prepass_tris)},
@@ -318,6 +328,7 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
     st = r.GetSettings()
     st.SceneMode, st.Bounces, st.TraversalOrder = cfg["mode"], cfg["bounces"], ORDERS[order_name]
     r.OnResize(w, h)
+    r.set_kernel_timing(KERNEL_TIMING_EVERY)
     r.upload(scene, cam)
     r.reset_accum()
     for f in range(1, warmup + 1):
@@ -396,6 +407,7 @@ def main():
     stream = torch.cuda.Stream()                     # one stream for the kernels and the collective that follows them
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
+    r.set_kernel_timing(KERNEL_TIMING_EVERY)
     r.upload(scene, cam)
 
     def barrier():

@@ -251,6 +251,11 @@ int rt_reset_counters(rt_ctx*);
 int rt_read_wave_clock(rt_ctx*, uint64_t* out, uint32_t max_waves, uint32_t* n_waves);
 int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
 int rt_reset_kernel_time(rt_ctx*);
+/* Which launches are timed.  A context times nothing until rt_get_kernel_time or rt_reset_kernel_time is called for the first
+   time (the event records around a launch cost a 1080p sphere frame about 5 % of its time: a caller that never asks never
+   pays); from then on every launch, or with rt_set_kernel_timing(ctx, n) every n-th launch, the first one after a reset
+   included (n = 0: none).  rt_kernel_time::launches / frames count the timed launches.  No counterpart in the reference. */
+int rt_set_kernel_timing(rt_ctx*, uint32_t every);
 /* Device addresses (for collectives over the buffers): accumulation is width*height float4 (rgb + unused w),
    image is width*height float4 RGBA. */
 void* rt_device_accum(rt_ctx*);

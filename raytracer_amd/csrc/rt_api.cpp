@@ -105,6 +105,7 @@ struct rt_ctx {
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
     uint32_t last_grid_waves = 0;
+    uint32_t timing_every = 0, timing_count = 0;        // kernel times: 0 = nobody has asked yet; else events around every n-th launch
     unsigned resume_lanes = 1;              // parked paths per wave of a resume launch (RT_RESUME_LANES=<1..64, a power of two> overrides)
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
     std::vector<float4> h_materials;     // packed materials as uploaded
@@ -1108,6 +1109,9 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     }
     // events: [pre, start) = what precedes the trace kernel on mesh scenes (the column pre-pass when the camera has direction.x == +0
     // pixels, the launch that stores first hits), [start, stop) = the trace kernel
+    // (only while someone asks for kernel times, and then around every timing_every-th launch: the two event records of a launch cost
+    // a 1080p sphere frame 8 us of its 150, the markers keep the next launch from being set up behind the running one)
+    const bool timed = c->timing_every != 0u && c->timing_count++ % c->timing_every == 0u;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     c->tests_may_overflow = tree && !tri_tests_stay_finite(c);
     const bool columns = tree && c->n_columns && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
@@ -1115,8 +1119,8 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // one of those changed and its result (the best hit per column ray) is kept.  The counting kernels always run it: their
     // counters describe what the reference's walk costs for these rays.
     const bool prepass = columns && (!c->column_cache || c->stats);
-    c->ev_has_pre[ev] = prepass || store_first;
-    if (c->ev_has_pre[ev]) HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
+    if (timed) c->ev_has_pre[ev] = prepass || store_first;
+    if (timed && c->ev_has_pre[ev]) HIP_TRY(c, hipEventRecord(c->ev_pre[ev], c->stream));
     if (prepass) {
         LAUNCH_TRY(c, rt_launch_column_prepass(&p, c->stats ? 1 : 0, c->stream));
         c->column_cache = true;
@@ -1134,11 +1138,10 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // sphere frames resolve inside the trace kernel; the 3x3 filter needs the neighbours' sums and keeps the separate pass
     const bool fused = !tree && !c->settings.anti_aliasing;
     p.fuse_resolve = fused ? 1u : 0u;
-    HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
+    if (timed) HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
-    if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, c->ev_stop[ev])) return rc;
-    c->ev_frames[ev] = n;
-    c->ev_head++;
+    if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, timed ? c->ev_stop[ev] : nullptr)) return rc;
+    if (timed) { c->ev_frames[ev] = n; c->ev_head++; }
     if (skip_empty) {
         c->host_rays += (unsigned long long)c->empty_pixels * n;
         if (!reuse) { c->host_entry_nodes += (unsigned long long)c->entry_nodes * n; c->host_entry_tris += (unsigned long long)c->entry_tris * n; }
@@ -1378,6 +1381,14 @@ int rt_get_kernel_time(rt_ctx* c, rt_kernel_time* out)
     DeviceGuard g(c->device);
     if (int rc = collect_time(c, true)) return rc;
     *out = c->ktime;
+    if (!c->timing_every) c->timing_every = 1;          // someone asks: from now on the launches are timed
+    return RT_OK;
+}
+
+int rt_set_kernel_timing(rt_ctx* c, uint32_t every)
+{
+    if (!c) return RT_E_ARG;
+    c->timing_every = every; c->timing_count = 0;
     return RT_OK;
 }
 
@@ -1387,6 +1398,8 @@ int rt_reset_kernel_time(rt_ctx* c)
     DeviceGuard g(c->device);
     if (int rc = collect_time(c, true)) return rc;
     c->ktime = rt_kernel_time{0, 0.0, 0.0, 0.0, 0};
+    if (!c->timing_every) c->timing_every = 1;
+    c->timing_count = 0;                                // the first launch after a reset is a timed one
     return RT_OK;
 }
 

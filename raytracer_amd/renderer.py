@@ -335,6 +335,10 @@ class Renderer:
             check(self._h, self._L.rt_reset_kernel_time(self._h), "rt_reset_kernel_time")
         return t
 
+    def set_kernel_timing(self, every):
+        """Events around every `every`-th launch only (0: none); see rt_set_kernel_timing."""
+        check(self._h, self._L.rt_set_kernel_timing(self._h, int(every)), "rt_set_kernel_timing")
+
     def device_accum_ptr(self):
         return self._L.rt_device_accum(self._h)
 
