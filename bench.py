@@ -54,11 +54,16 @@ CONFIGS = {
 }
 
 
-KERNEL_TIMING_EVERY = 8
-KERNEL_TIME_SOURCE = ("HIP events on the launch stream around every %dth launch of the timed region, the first included (the two event "
-                      "records of a launch cost a 1080p sphere frame about 8 us: timing every launch slows what is being timed; a timed launch stands "
-                      "alone between its two markers and its time includes its own dispatch, while an untimed launch is set up behind the "
-                      "running one, so ms_per_step can come out slightly below kernel_avg_ms)" % KERNEL_TIMING_EVERY)
+KERNEL_TIME_SOURCE = ("HIP events on the launch stream around every n-th single-Render launch of the timed region (n = steps / 4, at most 8; "
+                      "launches n / 2, n / 2 + n, ...; every launch where launches hold 16 Renders): the two event records of a launch cost a "
+                      "1080p sphere frame about 8 us, so timing every launch slows what is being timed; a timed launch stands alone between "
+                      "its two markers and its time includes its own dispatch, while an untimed launch is set up behind the running one, so "
+                      "ms_per_step can come out slightly below kernel_avg_ms")
+
+
+def timing_every(steps, per_launch=1):
+    """Which launches get HIP events (rt_set_kernel_timing): see KERNEL_TIME_SOURCE."""
+    return 1 if per_launch > 1 else max(1, min(8, steps // 4))
 
 
 def host_threads():
@@ -246,6 +251,7 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
 
 def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=None, n_spheres=9):
     """The same workload as launches of FRAMES_PER_LAUNCH Renders (rt_render_frames): what a progressive accumulation uses."""
+    r.set_kernel_timing(1)
     r.reset_accum(); r.render_only(1001, FRAMES_PER_LAUNCH)                     # warm: slot planes are allocated here
     r.sync(); torch.cuda.synchronize()
     r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
@@ -279,6 +285,7 @@ def first_hit_reuse(r, st, cfg, torch, steps, launches):
     out = {"note": "primary hits kept per pixel while camera, directions and tree are unchanged (found by one extra launch, "
                    "outside the timed region like the other per-camera set-up); frames are bit-identical to those without it"}
     for name, per, n in (("one_render_per_launch", 1, steps), ("throughput_mode", FRAMES_PER_LAUNCH, launches)):
+        r.set_kernel_timing(timing_every(n, per))
         r.reset_accum(); r.render_only(1001, per); r.sync(); torch.cuda.synchronize()
         r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
         t0 = time.perf_counter()
@@ -328,7 +335,7 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
     st = r.GetSettings()
     st.SceneMode, st.Bounces, st.TraversalOrder = cfg["mode"], cfg["bounces"], ORDERS[order_name]
     r.OnResize(w, h)
-    r.set_kernel_timing(KERNEL_TIMING_EVERY)
+    r.set_kernel_timing(timing_every(steps))
     r.upload(scene, cam)
     r.reset_accum()
     for f in range(1, warmup + 1):
@@ -407,7 +414,6 @@ def main():
     stream = torch.cuda.Stream()                     # one stream for the kernels and the collective that follows them
     torch.cuda.set_stream(stream)
     r.set_stream(stream.cuda_stream)
-    r.set_kernel_timing(KERNEL_TIMING_EVERY)
     r.upload(scene, cam)
 
     def barrier():
@@ -440,6 +446,7 @@ def main():
     torch.cuda.synchronize(); barrier()
 
     per_launch = FRAMES_PER_LAUNCH if args.profile == "throughput" else 1
+    r.set_kernel_timing(timing_every(K, per_launch))
     t0 = time.perf_counter()
     for f in frames[::per_launch]:                   # every rank starts from a zeroed buffer (rt_reset_accum)
         r.render_only(f, per_launch)

@@ -253,8 +253,9 @@ int rt_get_kernel_time(rt_ctx*, rt_kernel_time* out);
 int rt_reset_kernel_time(rt_ctx*);
 /* Which launches are timed.  A context times nothing until rt_get_kernel_time or rt_reset_kernel_time is called for the first
    time (the event records around a launch cost a 1080p sphere frame about 5 % of its time: a caller that never asks never
-   pays); from then on every launch, or with rt_set_kernel_timing(ctx, n) every n-th launch, the first one after a reset
-   included (n = 0: none).  rt_kernel_time::launches / frames count the timed launches.  No counterpart in the reference. */
+   pays); from then on every launch, or with rt_set_kernel_timing(ctx, n) every n-th launch: launches n / 2, n / 2 + n, ...
+   counted from the call or from the last rt_reset_kernel_time (n = 0: none).  rt_kernel_time::launches / frames count the
+   timed launches.  No counterpart in the reference. */
 int rt_set_kernel_timing(rt_ctx*, uint32_t every);
 /* Device addresses (for collectives over the buffers): accumulation is width*height float4 (rgb + unused w),
    image is width*height float4 RGBA. */

@@ -1111,7 +1111,8 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // pixels, the launch that stores first hits), [start, stop) = the trace kernel
     // (only while someone asks for kernel times, and then around every timing_every-th launch: the two event records of a launch cost
     // a 1080p sphere frame 8 us of its 150, the markers keep the next launch from being set up behind the running one)
-    const bool timed = c->timing_every != 0u && c->timing_count++ % c->timing_every == 0u;
+    // (launch n / 2 of every n: not the first after a reset, which starts on an idle chip and takes longer to get going)
+    const bool timed = c->timing_every != 0u && c->timing_count++ % c->timing_every == c->timing_every / 2u;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     c->tests_may_overflow = tree && !tri_tests_stay_finite(c);
     const bool columns = tree && c->n_columns && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
@@ -1399,7 +1400,7 @@ int rt_reset_kernel_time(rt_ctx* c)
     if (int rc = collect_time(c, true)) return rc;
     c->ktime = rt_kernel_time{0, 0.0, 0.0, 0.0, 0};
     if (!c->timing_every) c->timing_every = 1;
-    c->timing_count = 0;                                // the first launch after a reset is a timed one
+    c->timing_count = 0;
     return RT_OK;
 }
 
