@@ -592,6 +592,40 @@ def test_tile_split_with_the_3x3_filter(rt, orc, renderer, mode):
     assert np.array_equal(bits(img.reshape(-1, 4)), bits(want["img"]))
 
 
+def test_kernel_times_are_taken_only_when_asked_for(rt, orc):
+    """A context records no events around its launches until it is asked for kernel times; from then on around every launch, or
+    around launch n / 2 of every n (rt_set_kernel_timing), counted from the last reset.  The frames do not depend on it."""
+    scene, osc = make_scene(rt, orc)
+    w, h = 96, 64
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    r = rt.Renderer(0)
+    st = r.GetSettings(); st.SceneMode, st.Bounces = 1, 3
+    r.OnResize(w, h)
+    for _ in range(5): r.Render(scene, cam)
+    assert r.kernel_time().launches == 0                     # nobody had asked
+    for _ in range(3): r.Render(scene, cam)
+    kt = r.kernel_time(reset=True)
+    assert kt.launches == 3 and kt.frames == 3 and kt.total_ms > 0.0
+    r.set_kernel_timing(4)
+    for _ in range(10): r.Render(scene, cam)                 # launches 2 and 6 of 0..9
+    assert r.kernel_time(reset=True).launches == 2
+    r.Render(scene, cam, frames=3); r.Render(scene, cam, frames=3); r.Render(scene, cam, frames=3)     # launch 2 of 0..2, three Renders
+    kt = r.kernel_time()
+    assert kt.launches == 1 and kt.frames == 3
+    r.set_kernel_timing(0)
+    for _ in range(4): r.Render(scene, cam)
+    assert r.kernel_time().launches == 1
+    img = r.GetImage().data.copy()
+    r2 = rt.Renderer(0)
+    s2 = r2.GetSettings(); s2.SceneMode, s2.Bounces = 1, 3
+    r2.OnResize(w, h)
+    for _ in range(5 + 3 + 10 + 9 + 4): r2.Render(scene, cam)
+    r2.Render(scene, cam, frames=2)
+    r.Render(scene, cam, frames=2)
+    assert np.array_equal(bits(r.GetImage().data.reshape(-1, 4)), bits(r2.GetImage().data.reshape(-1, 4)))
+    assert img.shape == (h, w, 4)
+
+
 def test_pipelined_hand_off_returns_the_previous_frame(rt, orc, renderer):
     """rt_map_image_pipelined: the copy of frame k runs beside the trace of frame k + 1; each call returns the frame of the call
     before it (the first its own).  Every returned frame is bit-exact."""
