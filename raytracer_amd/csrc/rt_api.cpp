@@ -105,6 +105,7 @@ struct rt_ctx {
     DevBuf<int32_t> d_ids;
     DevBuf<unsigned long long> d_counters, d_wave_clock, d_column_stats;
     uint32_t last_grid_waves = 0;
+    bool heads_zero = false;                            // the ticket heads and park counters are zero on the stream (left so by the last resolve kernel)
     uint32_t timing_every = 0, timing_count = 0;        // kernel times: 0 = nobody has asked yet; else events around every n-th launch
     unsigned resume_lanes = 1;              // parked paths per wave of a resume launch (RT_RESUME_LANES=<1..64, a power of two> overrides)
     std::vector<float4> h_spheres;       // { center.xyz, radius^2 } as uploaded
@@ -1028,9 +1029,12 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
     if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
     if (c->tests_may_overflow) p.park_min_nodes = 0xFFFFFFFFu;          // (see tri_tests_stay_finite)
     const bool parking = tree && c->n_nodes >= p.park_min_nodes;
-    if (parking) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
-    // the unit tickets of tree scenes start at zero for every launch that draws units
-    if (tree) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
+    // The park counters and the unit tickets of tree scenes start at zero for every launch that draws units.  The resolve kernel
+    // that ends a Render leaves them so (rt_sum_resolve_kernel); they are filled here whenever the last launch sequence did not
+    // get as far as that kernel (the launch that stores first hits, an error on the way, the very first launch).
+    if (parking && !c->heads_zero) HIP_TRY(c, hipMemsetAsync(c->d_park_count.ptr, 0, 2 * sizeof(uint32_t), c->stream));
+    if (tree && !c->heads_zero) HIP_TRY(c, hipMemsetAsync(c->d_work_heads.ptr, 0, RT_WORK_HEADS * RT_HEAD_STRIDE * sizeof(uint32_t), c->stream));
+    if (tree) c->heads_zero = false;
     LAUNCH_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     if (stop) HIP_TRY(c, hipEventRecord(stop, c->stream));
     if (!parking) return RT_OK;
@@ -1149,7 +1153,7 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     }
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
-    if (tree) LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream));
+    if (tree) { LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, c->settings.anti_aliasing ? 0 : 1, c->stream)); c->heads_zero = true; }
     else if (!fused) LAUNCH_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
     if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
     return RT_OK;

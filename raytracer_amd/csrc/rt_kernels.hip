@@ -2249,6 +2249,11 @@ __global__ __launch_bounds__(RT_TREE_BLOCK) void rt_trace_kernel(RtParams p)
 // (Renderer.cpp:68-79).  One lane per pixel of a work unit; the rows bordering a band (halo units) only get their sums.
 __global__ __launch_bounds__(256) void rt_sum_resolve_kernel(RtParams p, uint32_t frame_index, int write_image)
 {
+    // The trace launch in front of this one has drawn its tickets and parked what it parked: the ticket heads and the two park
+    // counters start the next launch at zero, so this kernel leaves them so (the host then does without two fill launches per
+    // Render; it fills them itself whenever a launch sequence did not get as far as this kernel, see rt_ctx::heads_zero).
+    if (blockIdx.x == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < 2u && p.park_count) p.park_count[threadIdx.x] = 0u;
     const uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
     uint32_t pixel;
     if (unit >= p.n_units || !unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel)) return;
