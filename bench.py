@@ -54,16 +54,17 @@ CONFIGS = {
 }
 
 
-KERNEL_TIME_SOURCE = ("HIP events on the launch stream around every n-th single-Render launch of the timed region (n = steps / 4, at most 8; "
-                      "launches n / 2, n / 2 + n, ...; every launch where launches hold 16 Renders): the two event records of a launch cost a "
+KERNEL_TIME_SOURCE = ("HIP events on the launch stream; sphere scenes: around every n-th single-Render launch of the timed region (n = steps / 4, "
+                      "at most 8; launches n / 2, n / 2 + n, ...), tree scenes and launches of 16 Renders: around every launch.  The two event records of a launch cost a "
                       "1080p sphere frame about 8 us, so timing every launch slows what is being timed; a timed launch stands alone between "
                       "its two markers and its time includes its own dispatch, while an untimed launch is set up behind the running one, so "
                       "ms_per_step can come out slightly below kernel_avg_ms")
 
 
-def timing_every(steps, per_launch=1):
-    """Which launches get HIP events (rt_set_kernel_timing): see KERNEL_TIME_SOURCE."""
-    return 1 if per_launch > 1 else max(1, min(8, steps // 4))
+def timing_every(steps, per_launch=1, mode=1):
+    """Which launches get HIP events (rt_set_kernel_timing): see KERNEL_TIME_SOURCE.  Tree scenes: every launch (their frames
+    differ by +-10 % in kernel time, a sample of them would not give the mean; the events cost them 2 % at most)."""
+    return 1 if per_launch > 1 or mode != 1 else max(1, min(8, steps // 4))
 
 
 def host_threads():
@@ -285,7 +286,7 @@ def first_hit_reuse(r, st, cfg, torch, steps, launches):
     out = {"note": "primary hits kept per pixel while camera, directions and tree are unchanged (found by one extra launch, "
                    "outside the timed region like the other per-camera set-up); frames are bit-identical to those without it"}
     for name, per, n in (("one_render_per_launch", 1, steps), ("throughput_mode", FRAMES_PER_LAUNCH, launches)):
-        r.set_kernel_timing(timing_every(n, per))
+        r.set_kernel_timing(timing_every(n, per, cfg["mode"]))
         r.reset_accum(); r.render_only(1001, per); r.sync(); torch.cuda.synchronize()
         r.reset_accum(); r.reset_counters(); r.kernel_time(reset=True)
         t0 = time.perf_counter()
@@ -335,7 +336,7 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
     st = r.GetSettings()
     st.SceneMode, st.Bounces, st.TraversalOrder = cfg["mode"], cfg["bounces"], ORDERS[order_name]
     r.OnResize(w, h)
-    r.set_kernel_timing(timing_every(steps))
+    r.set_kernel_timing(timing_every(steps, 1, cfg["mode"]))
     r.upload(scene, cam)
     r.reset_accum()
     for f in range(1, warmup + 1):
@@ -446,7 +447,7 @@ def main():
     torch.cuda.synchronize(); barrier()
 
     per_launch = FRAMES_PER_LAUNCH if args.profile == "throughput" else 1
-    r.set_kernel_timing(timing_every(K, per_launch))
+    r.set_kernel_timing(timing_every(K, per_launch, cfg["mode"]))
     t0 = time.perf_counter()
     for f in frames[::per_launch]:                   # every rank starts from a zeroed buffer (rt_reset_accum)
         r.render_only(f, per_launch)
