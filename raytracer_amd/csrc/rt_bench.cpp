@@ -196,7 +196,8 @@ int main(int argc, char** argv)
     sync_all();
     for (uint32_t i = 0; i < n_dev; ++i) {
         rt_reset_counters(rt_group_ctx(g, (int)i)); rt_reset_kernel_time(rt_group_ctx(g, (int)i));
-        rt_set_kernel_timing(rt_group_ctx(g, (int)i), 8);              // events around every 8th launch: timing each one slows what is timed
+        // sphere frames one per launch: events around every 8th launch only (timing each one slows what is timed); else every launch
+        rt_set_kernel_timing(rt_group_ctx(g, (int)i), (o.per_launch > 1 || o.mode != 1) ? 1u : 8u);
     }
     frame_index = 1;
     const auto t0 = std::chrono::steady_clock::now();
