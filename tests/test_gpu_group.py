@@ -107,6 +107,7 @@ def test_rt_bench_headless_cpp_host():
         assert p.returncode == 0, (name, p.stderr[-400:])
         out[name] = json.loads(p.stdout.strip().splitlines()[-1])
         assert out[name]["frames"] == 8 and out[name]["ms_per_frame"] > 0 and out[name]["mrays_per_s"] > 0
+        assert out[name]["trace_kernel_ms_per_frame_gpu0"] > 0, name          # (some launch of every run is a timed one)
     rays = {name: o["rays_per_frame"] for name, o in out.items()}
     assert len(set(rays.values())) == 1 and rays["single"] >= 320 * 200, rays
     assert out["reuse"]["primary_hits_reused_per_frame"] > 0 and out["single"]["primary_hits_reused_per_frame"] == 0
