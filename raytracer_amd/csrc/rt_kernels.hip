@@ -2254,7 +2254,15 @@ __global__ __launch_bounds__(256) void rt_sum_resolve_kernel(RtParams p, uint32_
     // Render; it fills them itself whenever a launch sequence did not get as far as this kernel, see rt_ctx::heads_zero).
     if (blockIdx.x == 0 && threadIdx.x < RT_WORK_HEADS) p.work_heads[threadIdx.x * RT_HEAD_STRIDE] = 0u;
     if (blockIdx.x == 0 && threadIdx.x < 2u && p.park_count) p.park_count[threadIdx.x] = 0u;
-    const uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    // write_image bit 1: only the listed units (RtParams::unit_list).  The host asks for that while the units without a traced path
+    // hold what the first Render of the accumulation left there -- a sum of +0, its image and ids -- which further Renders, adding
+    // +0 each, would only write again unchanged.
+    uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    if (write_image & 2) {
+        if (unit >= p.n_list) return;
+        unit = p.unit_list[unit];
+    }
+    write_image &= 1;
     uint32_t pixel;
     if (unit >= p.n_units || !unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel)) return;
     const size_t plane = (size_t)p.width * p.height;
@@ -2533,7 +2541,8 @@ extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index,
 extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s)
 {
     const unsigned per_block = 256u / RT_UNIT;
-    hipLaunchKernelGGL(rt_sum_resolve_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p, frame_index, write_image);
+    const unsigned units = (write_image & 2) ? (p->n_list ? p->n_list : 1u) : p->n_units;      // (block 0 always runs: it zeroes the ticket heads)
+    hipLaunchKernelGGL(rt_sum_resolve_kernel, dim3((units + per_block - 1u) / per_block), dim3(256), 0, s, *p, frame_index, write_image);
     return hipGetLastError();
 }
 

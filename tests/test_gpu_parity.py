@@ -592,6 +592,54 @@ def test_tile_split_with_the_3x3_filter(rt, orc, renderer, mode):
     assert np.array_equal(bits(img.reshape(-1, 4)), bits(want["img"]))
 
 
+def test_units_without_a_traced_path_through_live_changes(rt, orc):
+    """Mesh-only scene, most work units without a primary ray into the tree.  After the first Render of an accumulation the resolve
+    pass visits only the listed units (the others hold a sum of +0, its image, ids of -1).  Whatever changes in the middle of the
+    accumulation -- the tone map, the id recording, the camera (units that had radiance become units without a path), the 3x3
+    filter on and off, several Renders per launch -- the frame, the sums and the ids stay the oracle's, bit for bit."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(24, x_range=(-0.8, 0.8), z_range=(-1.0, 1.0), mat_offset=0), spheres=False)
+    w, h = 160, 96
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    r = rt.Renderer(0)
+    st = r.GetSettings(); st.SceneMode, st.Bounces, st.UseACE_Color = 0, 4, True
+    r.OnResize(w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    frame = [1]
+
+    def step(frames=1, use_ace=True, aa=False):
+        st.UseACE_Color, st.AntiAliasing = use_ace, aa
+        r.Render(scene, cam, frames=frames)
+        dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+        ost = orc.Settings(1, 0, int(use_ace), int(aa), 4)
+        for _ in range(frames):
+            osc.render_frame(ost, cam.GetPosition(), dirs, w, h, frame[0], acc, img, seed=st.Seed)
+            frame[0] += 1
+        assert np.array_equal(bits(r.read_accum().reshape(-1, 3)), bits(acc)), "sums at frame %d" % (frame[0] - 1)
+        assert np.array_equal(bits(r.GetImage().data.reshape(-1, 4)), bits(img)), "image at frame %d" % (frame[0] - 1)
+
+    def oracle_ids():
+        ids = np.zeros(h * w, np.int32); a = np.zeros((h * w, 3), np.float32); i = np.zeros((h * w, 4), np.float32)
+        dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+        osc.render_frame(orc.Settings(1, 0, 1, 0, 4), cam.GetPosition(), dirs, w, h, 1, a, i, seed=st.Seed, primary_ids=ids)
+        return ids
+
+    step(); step(); step()
+    first = oracle_ids()
+    assert (first < 0).mean() > 0.5 and (first >= 0).mean() > 0.02          # most of the frame misses the mesh, some of it hits
+    step(use_ace=False); step(use_ace=True)                    # the tone map changes between Renders
+    r.record_ids(True); step()
+    assert np.array_equal(r.read_primary_ids().ravel(), oracle_ids())
+    cam.SetPose(np.array([0.9, 1.0, 3.0], np.float32), np.array([0.0, -0.1, -1.0], np.float32) / np.float32(np.sqrt(1.01)))
+    cam.OnResize(w, h)
+    step(); step(frames=3)                                     # the camera moved, the accumulation goes on
+    assert np.array_equal(r.read_primary_ids().ravel(), oracle_ids())
+    step(aa=True); step(aa=False); step(frames=2)              # the filter on for one Render
+    r.ResetFrameIndex(); acc[:] = 0; frame[0] = 1              # a new accumulation with the moved camera
+    step(); step(frames=4); step()
+    assert np.array_equal(r.read_primary_ids().ravel(), oracle_ids())
+
+
 def test_kernel_times_are_taken_only_when_asked_for(rt, orc):
     """A context records no events around its launches until it is asked for kernel times; from then on around every launch, or
     around launch n / 2 of every n (rt_set_kernel_timing), counted from the last reset.  The frames do not depend on it."""
