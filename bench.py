@@ -324,6 +324,45 @@ def with_d2h(r, torch, steps):
     return out
 
 
+def view_change(r, scene, cam, cfg, torch, steps):
+    """The camera-move frame: the reference restarts its accumulation whenever the camera moves (RaytracerApp.cpp:259-263,
+    Camera.cpp:21-103), so while the user navigates every Render is a first frame that follows a new rt_set_camera.  N Renders,
+    each after a slightly different pose, everything that a new view costs inside the timed region (ray directions, column
+    numbering, unit classification, pre-pass, full resolve).  `rotate`: the view direction turns by 2 mrad per Render about the
+    vertical axis (no pixel keeps direction.x == +0); `translate`: the camera moves 5 mm forward per Render (the centre column of
+    the default camera keeps direction.x == +0, so the column pre-pass runs every time)."""
+    import numpy as np
+    pos0, fwd0 = cam.GetPosition().copy(), cam.GetDirection().copy()
+    out = {"steps": steps, "note": "ms per Render, each Render preceded by rt_set_camera with a new pose and rendered as frame index 1; "
+                                   "all per-view set-up inside the timed region; image resident in HBM"}
+
+    def poses(kind, i):
+        if kind == "rotate":
+            a = np.float32(0.002 * (i + 1))
+            c, s_ = np.float32(np.cos(a)), np.float32(np.sin(a))
+            fwd = np.array([fwd0[0] * c + fwd0[2] * s_, fwd0[1], -fwd0[0] * s_ + fwd0[2] * c], np.float32)
+            return pos0, fwd
+        return (pos0 + fwd0 * np.float32(0.005 * (i + 1))).astype(np.float32), fwd0
+
+    try:
+        for kind in ("rotate", "translate"):
+            for i in range(3):                                   # warm: buffers of the per-view data are allocated here
+                cam.SetPose(*poses(kind, 100 + i)); r.upload(scene, cam); r.render_only(1)
+            r.sync(); torch.cuda.synchronize()
+            r.reset_counters()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                cam.SetPose(*poses(kind, i)); r.upload(scene, cam); r.render_only(1)
+            r.sync(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            cnt = r.read_counters()
+            out[kind] = {"ms_per_render": dt / steps * 1e3, "value": cnt.rays / dt / 1e6, "unit": "Mrays/s",
+                         "view_setups": int(cnt.view_setups)}
+    finally:
+        cam.SetPose(pos0, fwd0); r.upload(scene, cam)
+    return out
+
+
 def run_single(config_id, steps, warmup, order_name, torch, device=0):
     """One-GPU measurement of a configuration, one Render per launch, plus throughput mode.  Returns (record, scene, cam)."""
     import raytracer_amd as rt
@@ -358,6 +397,7 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
                                               roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))}
     if cfg["mode"] != 1:
         rec["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, steps, max(1, steps // FRAMES_PER_LAUNCH))
+    rec["view_change"] = view_change(r, scene, cam, cfg, torch, min(steps, 32))
     return rec, scene, cam, r
 
 
@@ -489,6 +529,8 @@ def main():
             if cfg["mode"] != 1:
                 out["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, K, max(1, K // FRAMES_PER_LAUNCH))
             out["with_d2h"] = with_d2h(r, torch, min(K, 32))
+            r.set_stream(stream.cuda_stream)
+            out["view_change"] = view_change(r, scene, cam, cfg, torch, min(K, 32))
         if not args.no_cpu_baseline and world == 1:             # the CPU oracle is timed beside the one-GPU run only
             n = args.cpu_frames or (16 if cfg["mode"] == 1 else 6)       # about 15-30 core-seconds of CPU work
             if cfg["mesh"] and cfg["mesh"][1] > 1000:

@@ -108,6 +108,11 @@ struct rt_ctx {
     // Mesh scenes: the units without a traced path hold what the first Render of the running accumulation left in them (a sum of +0,
     // its image, ids of -1), and every launch since was one that leaves them alone: the resolve pass then visits the listed units only.
     bool empties_settled = false, settled_record_ids = false;
+    // ... and, per frame buffer, whether those units' pixels hold that image: [0] is the buffer d_image names at the moment, [1] the
+    // back buffer of the pipelined hand-off.  The two change places at every rt_map_image_pipelined, and a Render may leave the empty
+    // units of the buffer it resolves into alone only if THAT buffer was resolved in full since the state was last dropped.
+    bool image_settled[2] = {false, false};
+    void unsettle() { empties_settled = false; image_settled[0] = image_settled[1] = false; }
     bool heads_zero = false;                            // the ticket heads and park counters are zero on the stream (left so by the last resolve kernel)
     uint32_t timing_every = 0, timing_count = 0;        // kernel times: 0 = nobody has asked yet; else events around every n-th launch
     unsigned resume_lanes = 1;              // parked paths per wave of a resume launch (RT_RESUME_LANES=<1..64, a power of two> overrides)
@@ -473,7 +478,7 @@ int rt_resize(rt_ctx* c, uint32_t w, uint32_t h)
         c->d_accum.release(); c->d_image.release(); c->d_ids.release(); c->d_dirs.release();
         return fail(c, e == hipErrorOutOfMemory ? RT_E_NOMEM : RT_E_HIP, "rt_resize(%u, %u): %s", w, h, hipGetErrorString(e));
     }
-    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_complete = true; c->empties_settled = false;
+    c->use_host_dirs = false; c->dirs_dirty = true; c->columns_dirty = true; c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_complete = true; c->unsettle();
     c->width = w; c->height = h;
     return RT_OK;
 }
@@ -484,7 +489,7 @@ int rt_set_settings(rt_ctx* c, const rt_settings* s)
     if (s->scene_mode < 0 || s->scene_mode > 2) return fail(c, RT_E_ARG, "scene_mode %d", s->scene_mode);
     if (s->traversal < RT_ORDER_AUTO || s->traversal > RT_ORDER_FRONT_TO_BACK) return fail(c, RT_E_ARG, "traversal %d", s->traversal);
     if (s->scene_mode != c->settings.scene_mode || s->traversal != c->settings.traversal) { c->first_hits_valid = false; c->units_valid = false; }
-    if (memcmp(s, &c->settings, sizeof *s) != 0) c->empties_settled = false;
+    if (memcmp(s, &c->settings, sizeof *s) != 0) c->unsettle();
     c->settings = *s;
     return RT_OK;
 }
@@ -906,7 +911,7 @@ int rt_set_ray_dirs(rt_ctx* c, const float* xyz, size_t n)
 int rt_set_bands(rt_ctx* c, uint32_t band_index, uint32_t band_count)
 {
     if (!c || !band_count || band_index >= band_count) return fail(c, RT_E_ARG, "rt_set_bands(%u, %u)", band_index, band_count);
-    if (band_index != c->band_index || band_count != c->band_count) { c->columns_dirty = true; c->empties_settled = false; }
+    if (band_index != c->band_index || band_count != c->band_count) { c->columns_dirty = true; c->unsettle(); }
     c->band_index = band_index; c->band_count = band_count;
     return RT_OK;
 }
@@ -973,7 +978,7 @@ int ensure_units(rt_ctx* c, RtParams& p, bool ordered)
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         c->entry_nodes = counts[0]; c->entry_tris = counts[1];
         c->units_valid = true; c->view_setups++;
-        c->empties_settled = false;
+        c->unsettle();
     }
     p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr; p.unit_entry = c->d_unit_entry.ptr;
     return RT_OK;
@@ -1104,8 +1109,8 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (skip_empty) { if (int rc = ensure_units(c, p, ordered)) return rc; }
     const uint32_t n_traced_units = skip_empty ? p.n_list : p.n_units;
     const bool plain_tree = skip_empty && !c->settings.anti_aliasing && !p.halo;         // (see rt_ctx::empties_settled)
-    if (!plain_tree) c->empties_settled = false;
-    const bool listed_only = plain_tree && c->empties_settled && frame_index != 1u && c->settled_record_ids == c->record_ids;
+    if (!plain_tree) c->unsettle();
+    const bool listed_only = plain_tree && c->empties_settled && c->image_settled[0] && frame_index != 1u && c->settled_record_ids == c->record_ids;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, ordered, n_traced_units * (tree ? n : 1u), grid)) return rc;
     // rt_settings.reuse_first_hits: the primary ray of a pixel and its mesh hit are the same in every Render while camera,
@@ -1164,7 +1169,9 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (tree) {
         LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, (c->settings.anti_aliasing ? 0 : 1) | (listed_only ? 2 : 0), c->stream));
         c->heads_zero = true;
-        if (plain_tree && frame_index == 1u) { c->empties_settled = true; c->settled_record_ids = c->record_ids; }
+        // a pass over every unit leaves the units without a path with their sum of +0, their ids and, in the buffer it wrote, their image
+        if (plain_tree && frame_index == 1u) c->empties_settled = true;
+        if (plain_tree && c->empties_settled && !listed_only) { c->image_settled[0] = true; c->settled_record_ids = c->record_ids; }
     }
     else if (!fused) LAUNCH_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
     if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
@@ -1202,7 +1209,7 @@ int rt_resolve(rt_ctx* c, uint32_t frame_index)
     RtParams p; fill_params(c, p, frame_index, 1);
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;
-    c->latest_in_back = false; c->empties_settled = false;
+    c->latest_in_back = false; c->unsettle();
     LAUNCH_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
     if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;
@@ -1215,7 +1222,7 @@ int rt_reset_accum(rt_ctx* c)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_accum.ptr, 0, (size_t)c->width * c->height * sizeof(float4), c->stream));
     c->halo_complete = true;                             // an empty sum is complete for every row
-    c->empties_settled = false;
+    c->unsettle();
     return RT_OK;
 }
 
@@ -1287,12 +1294,14 @@ const float* rt_map_image_pipelined(rt_ctx* c)
         if (hipStreamSynchronize(c->stream) != hipSuccess || c->d_image_back.resize(n) != hipSuccess) {
             fail(c, RT_E_NOMEM, "second frame buffer of %zu bytes", bytes); return nullptr;
         }
+        c->image_settled[1] = false;                     // fresh memory: no unit of it holds a frame
     }
     // The finished frame becomes the back buffer and is copied out over the copy stream; later Renders resolve into the other
     // buffer, whose own copy (two calls ago) was waited for before that call returned.
     const unsigned i = c->h_image_next & 1u;
     hipError_t e = hipEventRecord(c->frame_ready, c->stream);
     std::swap(c->d_image.ptr, c->d_image_back.ptr);
+    std::swap(c->image_settled[0], c->image_settled[1]);      // (see rt_ctx::image_settled)
     c->latest_in_back = true;
     if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->frame_ready, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(c->h_image[i], c->d_image_back.ptr, bytes, hipMemcpyDeviceToHost, c->copy_stream);
@@ -1434,7 +1443,7 @@ __attribute__((visibility("hidden"))) int rt_internal_resolve_from(rt_ctx* c, co
     p.accum = const_cast<float4*>(static_cast<const float4*>(accum_float4));
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;
-    c->latest_in_back = false; c->empties_settled = false;
+    c->latest_in_back = false; c->unsettle();
     LAUNCH_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
     if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
     return RT_OK;

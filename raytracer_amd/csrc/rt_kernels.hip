@@ -2033,7 +2033,9 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     woct = 0;
                     if (ORDERED) woct = (s.D.x < 0.0f ? 1u : 0u) | (s.D.y < 0.0f ? 2u : 0u) | (s.D.z < 0.0f ? 4u : 0u);
                     wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wsteps = 0;
-                    if (MODE == RT_MODE_MESH && !STATS && s.bounce == 1u && p.unit_entry) wnode = checked(p, p.unit_entry[pixel], end + 1u, 10);   // (see RtParams::unit_entry)
+                    // (see RtParams::unit_entry; a ray with direction.x == 0 had no say in its unit's entry node -- it gets here only
+                    // when the whole-wave walk above found a decision of its walk to depend on t -- and starts at the root)
+                    if (MODE == RT_MODE_MESH && !STATS && s.bounce == 1u && p.unit_entry && s.D.x != 0.0f) wnode = checked(p, p.unit_entry[pixel], end + 1u, 10);
                     wprune = FLT_MAX; wflag = false;
                     if (ORDERED && RT_NEAR_TIES) {
                         // The part of the near-tie distance that does not grow with t (see RtParams::tie_*): the rounding of a box's

@@ -701,6 +701,78 @@ def test_pipelined_hand_off_returns_the_previous_frame(rt, orc, renderer):
     assert np.array_equal(bits(renderer.map_image().reshape(-1, 4)), bits(frames[-1]))
 
 
+def test_pipelined_hand_off_of_a_mesh_scene_with_units_that_are_not_traced(rt, orc):
+    """The pipelined hand-off changes frame buffers at every call, and in a mesh-only scene the resolve pass of the later Renders
+    of an accumulation leaves the units without a traced path alone.  Each of the two buffers must have been resolved in full
+    before that: every frame shown -- through four accumulated frames, a camera move, a restart -- is the oracle's, bit for bit."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(24, x_range=(-0.8, 0.8), z_range=(-1.0, 1.0), mat_offset=0), spheres=False)
+    w, h = 160, 96
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    r = rt.Renderer(0)
+    st = r.GetSettings(); st.SceneMode, st.Bounces, st.UseACE_Color = 0, 4, True
+    r.OnResize(w, h)
+    r.pipelined = True
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32)
+    shown = []                                              # the oracle's frames in the order they were rendered
+    frame = 1
+
+    def step():
+        nonlocal frame
+        dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+        osc.render_frame(orc.Settings(1, 0, int(st.UseACE_Color), 0, 4), cam.GetPosition(), dirs, w, h, frame, acc, img, seed=st.Seed)
+        frame += 1
+        shown.append(img.copy())
+        r.Render(scene, cam)
+        want = shown[-2] if len(shown) > 1 else shown[-1]  # each call returns the frame of the call before it (the first its own)
+        assert np.array_equal(bits(r.GetImage().data.reshape(-1, 4)), bits(want)), "call %d" % len(shown)
+        assert np.array_equal(bits(r.read_image().reshape(-1, 4)), bits(shown[-1])), "newest frame at call %d" % len(shown)
+
+    for _ in range(5): step()
+    assert (shown[-1][:, :3].sum(axis=1) == 0).mean() > 0.5          # most of the frame belongs to units without a path
+    cam.SetPose(np.array([0.9, 1.0, 3.0], np.float32), np.array([0.0, -0.1, -1.0], np.float32) / np.float32(np.sqrt(1.01)))
+    cam.OnResize(w, h)
+    for _ in range(4): step()                              # the camera moved, the accumulation goes on (other units are empty now)
+    r.ResetFrameIndex(); acc[:] = 0; frame = 1
+    for _ in range(5): step()                              # a new accumulation
+    st.UseACE_Color = False
+    r.ResetFrameIndex(); acc[:] = 0; frame = 1
+    for _ in range(3): step()                              # ... and one without the tone map
+    assert np.array_equal(bits(r.read_accum().reshape(-1, 3)), bits(acc))
+
+
+def test_minus_zero_x_direction_primaries_in_a_mesh_only_scene(rt, orc, renderer):
+    """Primary rays with direction.x == -0 are no column rays (those have +0): in a mesh-only scene their wave walks the tree for
+    them, and they take no part in finding the node at which their unit's other primary walks start.  Host-supplied directions
+    with -0 and +0 planted in x across whole units and in single pixels; ids, sums and image are the oracle's in both orders."""
+    from raytracer_amd import scenes
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(40, mat_offset=0), spheres=False)
+    w, h = 96, 64
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h).reshape(h, w, 3).copy()
+    dirs[10:40, 20, 0] = -0.0                               # a column of -0 through many units
+    dirs[30, 40:60, 0] = -0.0                               # a row: whole units of -0
+    dirs[34, 41:57:3, 0] = 0.0                              # +0 and -0 mixed with ordinary rays inside units
+    dirs[35, 42:58:3, 0] = -0.0
+    dirs = dirs.reshape(-1, 3)
+    for order in (REF_ORDER, F2B_ORDER):
+        st = renderer.GetSettings()
+        st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed, st.TraversalOrder = 0, 4, True, False, True, 1337, order
+        renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True)
+        renderer.upload(scene, cam); renderer.set_ray_dirs(dirs)
+        acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
+        try:
+            for f in range(1, 4):
+                renderer.Render(scene, cam)
+                osc.render_frame(orc.Settings(1, 0, 1, 0, 4), cam.GetPosition(), dirs, w, h, f, acc, img, primary_ids=ids if f == 1 else None)
+            got = dict(ids=renderer.read_primary_ids().ravel(), acc=renderer.read_accum().reshape(-1, 3),
+                       img=renderer.GetImage().data.reshape(-1, 4), cnt=None)
+        finally:
+            renderer.set_ray_dirs(None); st.TraversalOrder = 0
+        assert_exact(got, dict(ids=ids, acc=acc, img=img, cnt=None), counters=())
+        assert (ids[(np.arange(h * w) % w == 20) & (np.arange(h * w) // w >= 10) & (np.arange(h * w) // w < 40)] >= 0).any()
+
+
 def test_sample_split_sum_matches_within_reassociation_tolerance(rt, orc, renderer):
     from raytracer_amd import dist as rtd
     scene, osc = make_scene(rt, orc)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""ms per Render while the camera moves (every Render a first frame after a new rt_set_camera): bench.view_change for one or
+more configurations.   python tools/view_change_probe.py 3 4 [--steps 16]"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def main():
+    import torch
+    import raytracer_amd as rt
+    argv = sys.argv[1:]
+    steps = 16
+    if "--steps" in argv:
+        i = argv.index("--steps"); steps = int(argv[i + 1]); del argv[i:i + 2]
+    args = argv
+    for cid in [int(a) for a in args] or [3]:
+        cfg = bench.CONFIGS[cid]
+        scene = bench.build_scene(cfg)
+        cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(cfg["w"], cfg["h"])
+        r = rt.Renderer(0); r.download = False
+        st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
+        r.OnResize(cfg["w"], cfg["h"]); r.upload(scene, cam)
+        for f in range(1, 4):
+            r.render_only(f)
+        r.sync()
+        print(json.dumps({"config": cid, "view_change": bench.view_change(r, scene, cam, cfg, torch, steps)}), flush=True)
+        del r, scene
+
+
+if __name__ == "__main__":
+    main()
