@@ -324,7 +324,7 @@ def with_d2h(r, torch, steps):
     return out
 
 
-def view_change(r, scene, cam, cfg, torch, steps):
+def view_change(r, scene, cam, cfg, torch, steps, kinds=("rotate", "translate")):
     """The camera-move frame: the reference restarts its accumulation whenever the camera moves (RaytracerApp.cpp:259-263,
     Camera.cpp:21-103), so while the user navigates every Render is a first frame that follows a new rt_set_camera.  N Renders,
     each after a slightly different pose, everything that a new view costs inside the timed region (ray directions, column
@@ -345,7 +345,7 @@ def view_change(r, scene, cam, cfg, torch, steps):
         return (pos0 + fwd0 * np.float32(0.005 * (i + 1))).astype(np.float32), fwd0
 
     try:
-        for kind in ("rotate", "translate"):
+        for kind in kinds:
             for i in range(3):                                   # warm: buffers of the per-view data are allocated here
                 cam.SetPose(*poses(kind, 100 + i)); r.upload(scene, cam); r.render_only(1)
             r.sync(); torch.cuda.synchronize()

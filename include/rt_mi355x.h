@@ -185,11 +185,22 @@ int rt_group_render_tiles(rt_group*, uint32_t frame_index, uint32_t n_frames);
    (|d| <= 1e-4 + 1e-4 |ref|).  rt_group_read_accum: that total, width*height*3 floats. */
 int rt_group_render_samples(rt_group*, uint32_t frame_first, uint32_t frames_per_ctx);
 int rt_group_read_accum(rt_group*, float* out_rgb);
+/* Diagnostics.  Both calls above issue the trace launch on every context before the host waits for any of them (in a tree
+   large enough for bounce rays with direction.x == 0 to be handed to whole-chip kernels, every launch is followed by a wait for
+   one word: how many paths it parked).  This returns how many of those launches were still running when the last call had
+   issued on all its contexts -- with several GPUs and frames of more than a few hundred microseconds, all of them; 0 when the
+   scene needs no such word; -1 before the first call. */
+int rt_group_issue_overlap(const rt_group*);
 
 /* ---- the hot path ---------------------------------------------------------------------------- */
 /* Renderer::Render (Renderer.cpp:45-135) for 1-based frame index `frame_index` (m_frameindex): trace, accumulate,
-   resolve, optional AA filter.  Asynchronous on the context's stream.  frame_index == 1 restarts accumulation
-   (Renderer.cpp:55-56). */
+   resolve, optional AA filter.  frame_index == 1 restarts accumulation (Renderer.cpp:55-56).  The work is queued on the
+   context's stream and the call returns without waiting for it, with one exception: in a tree of 2^18 nodes or more (2^12 with
+   spheres and mesh together) the call waits for its trace kernel to finish, because what follows it depends on one word the
+   kernel leaves behind -- the number of bounce rays with direction.x == 0 it handed to whole-chip kernels; the passes after
+   that (those rays' hits, the sums, the image) are again only queued.  Nothing else waits for the device once frame size,
+   scene and tree are in place: a new camera costs kernels, not round trips (the per-view counts the host keeps for
+   rt_read_counters come back behind the kernels). */
 int rt_render(rt_ctx*, uint32_t frame_index);
 /* n consecutive Render calls (frame_index .. frame_index+n-1) with the scene, camera and settings of the moment; identical
    accumulation (the per-frame values are added in frame order), only the last frame's image is resolved.  Sphere scenes: one

@@ -24,7 +24,7 @@ EXPORTS = [
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters", "rt_read_wave_clock",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_set_kernel_timing", "rt_device_accum", "rt_device_image",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_last_error", "rt_group_render_tiles",
-    "rt_group_render_samples", "rt_group_read_accum",
+    "rt_group_render_samples", "rt_group_read_accum", "rt_group_issue_overlap",
     "rt_host_camera_default_forward", "rt_host_camera_matrices", "rt_host_kd_build", "rt_host_kd_flat", "rt_host_kd_free",
 ]
 
@@ -103,7 +103,7 @@ def lib():
         "rt_group_create": ([vp, C.c_int], vp), "rt_group_destroy": ([vp], None), "rt_group_size": ([vp], C.c_int),
         "rt_group_ctx": ([vp, C.c_int], vp), "rt_group_last_error": ([vp], C.c_char_p),
         "rt_group_render_tiles": ([vp, u32, u32], C.c_int), "rt_group_render_samples": ([vp, u32, u32], C.c_int),
-        "rt_group_read_accum": ([vp, vp], C.c_int),
+        "rt_group_read_accum": ([vp, vp], C.c_int), "rt_group_issue_overlap": ([vp], C.c_int),
         "rt_host_camera_default_forward": ([vp], None),
         "rt_host_camera_matrices": ([f32, f32, f32, u32, u32] + [vp] * 6, None),
         "rt_host_kd_build": ([vp, u32, vp, u32, u32, C.c_int], vp),

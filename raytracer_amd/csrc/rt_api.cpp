@@ -29,7 +29,8 @@ extern "C" hipError_t rt_launch_raygen(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s);
 extern "C" hipError_t rt_launch_column_prepass(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s);
-extern "C" hipError_t rt_launch_units_entry(const RtParams* p, hipStream_t s);
+extern "C" hipError_t rt_launch_units_entry(const RtParams* p, unsigned max_listed, hipStream_t s);
+extern "C" unsigned rt_units_blocks(unsigned n_units);
 extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_index, int write_image, hipStream_t s);
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
@@ -95,9 +96,23 @@ struct rt_ctx {
     bool first_hits_valid = false;       // ... and whether it belongs to the current camera, directions, bands, tree and walk order
     // mesh-only scenes: the work units in which a primary ray can hit anything (the others are not traced, see RtParams::unit_list)
     DevBuf<unsigned char> d_unit_empty;
-    DevBuf<uint32_t> d_unit_list, d_unit_counts, d_unit_entry;
+    DevBuf<uint32_t> d_unit_list, d_unit_counts, d_unit_entry, d_unit_block;
     bool units_valid = false;            // they belong to the current camera, directions, bands and tree
+    bool entry_valid = false;            // ... and so do the entry nodes of the listed units' primary walks (found from the second Render of a view on)
+    uint32_t view_age = 0;               // Renders made with the current unit list
+    uint32_t entry_delay = 1;            // Renders a view must have seen before its entry nodes are worth finding (RT_ENTRY_DELAY=<n> overrides)
     uint32_t n_list = 0, empty_pixels = 0, entry_nodes = 0, entry_tris = 0;
+    // What the device finds per view and the host needs for its book-keeping only (and for the size of a few grids) comes back
+    // behind the kernels, into page-locked memory, and is looked at when it has arrived: no launch waits for it.
+    // h_view: [0] column rays, [1] listed units, [2] pixels of empty units, [3] / [4] node steps / triangle tests the entry nodes spare one Render
+    uint32_t* h_view = nullptr;
+    hipEvent_t ev_columns = nullptr, ev_units = nullptr, ev_entry = nullptr;
+    bool columns_pending = false, units_pending = false, entry_pending = false;     // the copy is queued and has not been seen to arrive
+    bool columns_known = true, units_known = false, entry_known = false;            // the host fields above hold this view's values
+    unsigned long long owed_unit_frames = 0, owed_entry_frames = 0;                 // Renders whose untraced rays / spared steps are not in the host counters yet
+    // the word the main trace launch parks paths under, read back behind it (see trace_issue / trace_finish)
+    uint32_t* h_parked = nullptr;
+    hipEvent_t parked_ready = nullptr;
     unsigned long long host_entry_nodes = 0, host_entry_tris = 0;    // steps the entry points spared the primary walks
     unsigned long long host_rays = 0;    // primary rays of empty units: TraceRay invocations that needed no kernel
     unsigned long long view_setups = 0;  // times the unit list or the first hits were built
@@ -151,7 +166,7 @@ struct rt_ctx {
     DevBuf<uint32_t> d_park_queue_count;
     static const uint32_t kParkQueueCap = 1u << 22;        // pairs per family (32 MB); beyond it the filter tests in place
     DevBuf<unsigned long long> d_column_best;
-    DevBuf<unsigned char> d_reached;
+    DevBuf<unsigned long long> d_reached;
     DevBuf<uint32_t> d_rec_leaf;                        // per leaf record: the node index of its leaf (4 bytes instead of the record's 48)
     bool columns_dirty = true;
     uint32_t n_columns = 0;              // host copy of the count (read back once per change)
@@ -369,7 +384,14 @@ rt_ctx* rt_create(int device_id)
     for (int i = 0; ok && i < rt_ctx::UP_RING; ++i) ok = hipEventCreateWithFlags(&c->up_done[i], hipEventDisableTiming) == hipSuccess;
     for (int i = 0; ok && i < 2; ++i) ok = hipEventCreateWithFlags(&c->h_image_done[i], hipEventDisableTiming) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-         hipEventCreateWithFlags(&c->frame_ready, hipEventDisableTiming) == hipSuccess;
+         hipEventCreateWithFlags(&c->frame_ready, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_columns, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_units, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->ev_entry, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&c->parked_ready, hipEventDisableTiming) == hipSuccess &&
+         hipHostMalloc((void**)&c->h_view, 8 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess &&
+         hipHostMalloc((void**)&c->h_parked, 2 * sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+    if (ok) { memset(c->h_view, 0, 8 * sizeof(uint32_t)); memset(c->h_parked, 0, 2 * sizeof(uint32_t)); }
     if (!ok) {
         fail(nullptr, RT_E_HIP, "stream/event creation failed on device %d", device_id);
         rt_destroy(c); return nullptr;
@@ -402,6 +424,7 @@ rt_ctx* rt_create(int device_id)
     c->n_cus = prop.multiProcessorCount;
     (void)rt_static_setup(device_id);      // set-up of rt_render_spheres_noalloc on this device (it reports a failure itself when called)
     if (const char* e = getenv("RT_RESUME_LANES")) { const int v = atoi(e); if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->resume_lanes = (unsigned)v; }
+    if (const char* e = getenv("RT_ENTRY_DELAY")) { const int v = atoi(e); if (v >= 0) c->entry_delay = (uint32_t)v; }
     if (const char* e = getenv("RT_PARK_MIN_NODES")) { const long v = atol(e); if (v >= 1) { c->park_min_nodes = (uint32_t)v; c->park_min_forced = true; } }
     return c;
 }
@@ -425,7 +448,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
     c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release();
-    c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release(); c->d_unit_entry.release();
+    c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release(); c->d_unit_entry.release(); c->d_unit_block.release();
     for (int i = 0; i < rt_ctx::UP_RING; ++i) {
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
         if (c->up_buf[i]) (void)hipHostFree(c->up_buf[i]);
@@ -435,6 +458,9 @@ void rt_destroy(rt_ctx* c)
         if (c->h_image[i]) (void)hipHostFree(c->h_image[i]);
     }
     if (c->frame_ready) (void)hipEventDestroy(c->frame_ready);
+    for (hipEvent_t ev : {c->ev_columns, c->ev_units, c->ev_entry, c->parked_ready}) if (ev) (void)hipEventDestroy(ev);
+    if (c->h_view) (void)hipHostFree(c->h_view);
+    if (c->h_parked) (void)hipHostFree(c->h_parked);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -768,8 +794,8 @@ int rt_set_kdtree(rt_ctx* c, const rt_kd_flat* kd)
     lap("eight node arrays made and copied");
     if (!recs.empty()) HIP_TRY(c, hipMemcpy(c->d_leafrecs.ptr, recs.data(), recs.size() * sizeof(float4), hipMemcpyHostToDevice));
     lap("leaf records copied");
-    HIP_TRY(c, c->d_reached.resize(M));
-    HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, M));
+    HIP_TRY(c, c->d_reached.resize(((size_t)M + 63) / 64));
+    HIP_TRY(c, hipMemset(c->d_reached.ptr, 0, c->d_reached.count * sizeof(unsigned long long)));
     {
         std::vector<uint32_t> rec_leaf(recs.size() / 3 + 1, 0u);
         in_chunks(recs.size() / 3, threads, [&](unsigned, size_t r_first, size_t r_last) {
@@ -927,7 +953,40 @@ int ensure_dirs(rt_ctx* c, const RtParams& p)
     return RT_OK;
 }
 
-// Column rays of the current directions/bands: slots into dirs[].w, count read back once (only when something changed).
+// The per-view counts that have arrived from the device (see rt_ctx::h_view) move into the host's fields, and the Renders made
+// before they were known are entered into the host-side counters.  `wait`: wait for the ones still on their way.
+int settle_view(rt_ctx* c, bool wait)
+{
+    auto arrived = [&](bool& pending, hipEvent_t ev) -> int {
+        if (!pending) return 0;
+        if (!wait) {
+            const hipError_t q = hipEventQuery(ev);
+            if (q == hipErrorNotReady) return 0;
+            if (q != hipSuccess) return -1;
+        } else if (hipEventSynchronize(ev) != hipSuccess) return -1;
+        pending = false;
+        return 1;
+    };
+    int r = arrived(c->columns_pending, c->ev_columns);
+    if (r < 0) return fail(c, RT_E_HIP, "waiting for the column count");
+    if (r) { c->n_columns = c->h_view[0]; c->columns_known = true; }
+    r = arrived(c->units_pending, c->ev_units);
+    if (r < 0) return fail(c, RT_E_HIP, "waiting for the unit counts");
+    if (r) { c->n_list = c->h_view[1]; c->empty_pixels = c->h_view[2]; c->units_known = true; }
+    r = arrived(c->entry_pending, c->ev_entry);
+    if (r < 0) return fail(c, RT_E_HIP, "waiting for the entry counts");
+    if (r) { c->entry_nodes = c->h_view[3]; c->entry_tris = c->h_view[4]; c->entry_known = true; }
+    if (c->units_known && c->owed_unit_frames) { c->host_rays += (unsigned long long)c->empty_pixels * c->owed_unit_frames; c->owed_unit_frames = 0; }
+    if (c->entry_known && c->owed_entry_frames) {
+        c->host_entry_nodes += (unsigned long long)c->entry_nodes * c->owed_entry_frames;
+        c->host_entry_tris += (unsigned long long)c->entry_tris * c->owed_entry_frames;
+        c->owed_entry_frames = 0;
+    }
+    return RT_OK;
+}
+
+// Column rays of the current directions/bands: slots into dirs[].w.  Their number comes back behind the kernels (rt_ctx::h_view);
+// until it has arrived the pre-pass is launched as if there were some (its kernels return at once when there are none).
 int ensure_columns(rt_ctx* c, RtParams& p)
 {
     // scratch for the per-block scans: one word per 256 pixels / 256 nodes / 256 slots, whichever is most
@@ -941,46 +1000,54 @@ int ensure_columns(rt_ctx* c, RtParams& p)
     if (c->halo_in_columns != (p.halo != 0u)) c->columns_dirty = true;      // the rows bordering the bands joined or left the frame
     if (!c->columns_dirty) return RT_OK;
     c->column_cache = false; c->first_hits_valid = false; c->units_valid = false; c->halo_in_columns = p.halo != 0u;
+    if (c->columns_pending) HIP_TRY(c, hipEventSynchronize(c->ev_columns));     // (the copy of the view before: long done)
     LAUNCH_TRY(c, rt_launch_column_collect(&p, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(&c->n_columns, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_view, c->d_column_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ev_columns, c->stream));
+    c->columns_pending = true; c->columns_known = false;
     c->columns_dirty = false;
     return RT_OK;
 }
 
-// Mesh-only scenes: which work units hold a primary ray that enters the root box (RtParams::unit_list); the two counts are read
-// back once per change, like the column count.
+// Mesh-only scenes: which work units hold a primary ray that enters the root box (RtParams::unit_list).  Three launches and no
+// wait: the trace kernel reads the length of the list on the device.  From the second Render of a view on, also the node at
+// which each listed unit's primary walks may start (RtParams::unit_entry): finding those costs about what they spare one Render,
+// so a view that lasts a single Render (the camera is being moved) does without.
 int ensure_units(rt_ctx* c, RtParams& p, bool ordered)
 {
     if (!c->units_valid) {
+        if (int rc = settle_view(c, true)) return rc;       // the view before: its counts have long arrived; its Renders are entered
         const size_t pixels = (size_t)c->width * c->height;
-        if (c->d_unit_entry.count != pixels) {
+        const size_t blocks = rt_units_blocks(p.n_units);
+        if (c->d_unit_entry.count != pixels || c->d_unit_empty.count < p.n_units || c->d_unit_block.count < blocks || !c->d_unit_counts.count) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             HIP_TRY(c, c->d_unit_entry.resize(pixels));
+            if (c->d_unit_empty.count < p.n_units) { HIP_TRY(c, c->d_unit_empty.resize(p.n_units)); HIP_TRY(c, c->d_unit_list.resize(p.n_units)); }
+            if (c->d_unit_block.count < blocks) HIP_TRY(c, c->d_unit_block.resize(blocks));
+            if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(4));
         }
-        if (c->d_unit_empty.count < p.n_units) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            HIP_TRY(c, c->d_unit_empty.resize(p.n_units));
-            HIP_TRY(c, c->d_unit_list.resize(p.n_units));
-        }
-        if (!c->d_unit_counts.count) HIP_TRY(c, c->d_unit_counts.resize(4));
         p.unit_empty_out = c->d_unit_empty.ptr; p.unit_list_out = c->d_unit_list.ptr; p.unit_counts_out = c->d_unit_counts.ptr;
-        HIP_TRY(c, hipMemsetAsync(c->d_unit_counts.ptr, 0, 4 * sizeof(uint32_t), c->stream));
+        p.unit_block_out = c->d_unit_block.ptr;
         LAUNCH_TRY(c, rt_launch_units_classify(&p, c->stream));
-        uint32_t counts[2] = {0, 0};
-        HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr, sizeof counts, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->n_list = counts[0]; c->empty_pixels = counts[1];
-        // where the primary walks of the listed units may start, for the walk order in use
-        p.n_list = c->n_list; p.unit_entry_out = c->d_unit_entry.ptr; p.entry_ordered = ordered ? 1u : 0u;
-        LAUNCH_TRY(c, rt_launch_units_entry(&p, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(counts, c->d_unit_counts.ptr + 2, sizeof counts, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        c->entry_nodes = counts[0]; c->entry_tris = counts[1];
-        c->units_valid = true; c->view_setups++;
+        HIP_TRY(c, hipMemcpyAsync(c->h_view + 1, c->d_unit_counts.ptr, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_units, c->stream));
+        c->units_pending = true; c->units_known = false; c->entry_pending = false; c->entry_known = false;
+        c->n_list = 0; c->empty_pixels = 0; c->entry_nodes = 0; c->entry_tris = 0;
+        c->units_valid = true; c->entry_valid = false; c->view_age = 0; c->view_setups++;
         c->unsettle();
     }
-    p.unit_list = c->d_unit_list.ptr; p.n_list = c->n_list; p.unit_empty = c->d_unit_empty.ptr; p.unit_entry = c->d_unit_entry.ptr;
+    if (!c->entry_valid && c->view_age >= c->entry_delay) {
+        // where the primary walks of the listed units may start, for the walk order in use
+        p.unit_list_out = c->d_unit_list.ptr; p.unit_counts_out = c->d_unit_counts.ptr;
+        p.unit_entry_out = c->d_unit_entry.ptr; p.entry_ordered = ordered ? 1u : 0u;
+        LAUNCH_TRY(c, rt_launch_units_entry(&p, c->units_known ? c->n_list : p.n_units, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_view + 3, c->d_unit_counts.ptr + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_entry, c->stream));
+        c->entry_pending = true; c->entry_known = false;
+        c->entry_valid = true;
+    }
+    p.unit_list = c->d_unit_list.ptr; p.unit_counts = c->d_unit_counts.ptr; p.n_list = c->units_known ? c->n_list : 0u;
+    p.unit_empty = c->d_unit_empty.ptr; p.unit_entry = c->entry_valid ? c->d_unit_entry.ptr : nullptr;
     return RT_OK;
 }
 
@@ -1029,16 +1096,19 @@ bool tri_tests_stay_finite(const rt_ctx* c)
 // it parked (bounce rays with direction.x == 0: none in most frames, the whole centre column behind a glass sphere that sits on
 // the camera's x).  Their hits by whole-chip kernels, family by family, then the rest of those paths by a small launch of the
 // trace kernel -- which may park again at a later bounce, into the other list: one round per bounce at most.  How many were
-// parked decides what is launched, so the host reads that one word back.  `stop`: event recorded right after the main launch.
-int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsigned grid, hipEvent_t stop)
+// parked decides what is launched, so the host needs that one word: trace_issue queues the launch and the word's copy into
+// page-locked memory and returns; trace_finish waits for the word and runs the rounds.  Between the two the caller may issue
+// on other contexts (rt_group_*: every GPU of a group is at work before the host waits for any of them).
+// `stop`: event recorded right after the main launch.  `parking`: out, whether trace_finish has anything to wait for.
+int trace_issue(rt_ctx* c, RtParams& p, int mode, bool ordered, unsigned grid, hipEvent_t stop, bool& parking)
 {
     const bool tree = mode != RT_SCENE_SPHERES;
     // With spheres and mesh together such rays are systematic (the centre column behind a sphere on the camera's x), so they are
-    // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back below costs more than
+    // parked in any but the smallest trees; in a tree-only scene they are one in 10^9 and the read-back costs more than
     // the rare walk by a wave, except in large trees.
     if (mode == RT_SCENE_BOTH && !c->park_min_forced && p.park_min_nodes > RT_PARK_MIN_NODES_MIXED) p.park_min_nodes = RT_PARK_MIN_NODES_MIXED;
     if (c->tests_may_overflow) p.park_min_nodes = 0xFFFFFFFFu;          // (see tri_tests_stay_finite)
-    const bool parking = tree && c->n_nodes >= p.park_min_nodes;
+    parking = tree && c->n_nodes >= p.park_min_nodes;
     // The park counters and the unit tickets of tree scenes start at zero for every launch that draws units.  The resolve kernel
     // that ends a Render leaves them so (rt_sum_resolve_kernel); they are filled here whenever the last launch sequence did not
     // get as far as that kernel (the launch that stores first hits, an error on the way, the very first launch).
@@ -1048,10 +1118,17 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
     LAUNCH_TRY(c, rt_launch_trace(&p, mode, c->stats ? 1 : 0, ordered ? 1 : 0, grid, c->stream));
     if (stop) HIP_TRY(c, hipEventRecord(stop, c->stream));
     if (!parking) return RT_OK;
-    uint32_t parked = 0;
+    HIP_TRY(c, hipMemcpyAsync(c->h_parked, c->d_park_count.ptr, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->parked_ready, c->stream));
+    return RT_OK;
+}
+
+int trace_finish(rt_ctx* c, RtParams& p, int mode, bool ordered, bool parking)
+{
+    if (!parking) return RT_OK;
+    HIP_TRY(c, hipEventSynchronize(c->parked_ready));
+    uint32_t parked = c->h_parked[0];
     int cur = 0;
-    HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr, sizeof parked, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (uint32_t round = 0; parked != 0; ++round) {
         const bool last = round + 1 >= c->settings.bounces;
         RtParams q = p;
@@ -1070,20 +1147,38 @@ int trace_and_finish_parked(rt_ctx* c, RtParams& p, int mode, bool ordered, unsi
         LAUNCH_TRY(c, rt_launch_trace(&q, mode, c->stats ? 1 : 0, ordered ? 1 : 0, (waves + waves_per_block - 1u) / waves_per_block, c->stream));
         if (last) break;
         cur = 1 - cur;
-        HIP_TRY(c, hipMemcpyAsync(&parked, c->d_park_count.ptr + cur, sizeof parked, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->h_parked, c->d_park_count.ptr + cur, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
+        parked = c->h_parked[0];
     }
     return RT_OK;
 }
 
-// Frames frame_index .. frame_index + n - 1 in one launch of the trace kernel (tree scenes: n <= RT_MAX_LAUNCH_FRAMES).
-int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
+}  // namespace
+
+// A launch that has been issued and not finished (render_issue / render_finish).
+struct rt_pending {
+    bool active = false, parking = false, tree = false, ordered = false, timed = false, skip_empty = false, reuse = false;
+    bool plain_tree = false, listed_only = false, fused = false;
+    int mode = 0;
+    unsigned ev = 0, gx = 0, gy = 0;
+    uint32_t frame_index = 0, n = 0;
+    RtParams p;
+};
+
+namespace {
+
+// Frames frame_index .. frame_index + n - 1 in one launch of the trace kernel (tree scenes: n <= RT_MAX_LAUNCH_FRAMES): everything
+// up to and including that launch.  Nothing here waits for the device while a view lasts (a new frame size or a larger tree does).
+int render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending& L)
 {
+    L = rt_pending();
     const int mode = c->settings.scene_mode;
     const bool tree = mode != RT_SCENE_SPHERES;
-    RtParams p; fill_params(c, p, frame_index, n);
+    RtParams& p = L.p; fill_params(c, p, frame_index, n);
     unsigned gx, gy; grid_for(c, gx, gy);
     if (!gy) return RT_OK;                              // this context owns no band of so small a frame
+    if (int rc = settle_view(c, false)) return rc;
     // The 3x3 filter under a tile split reads the sums of the rows bordering this context's bands.  They are traced and summed
     // like its own rows while the filter is on; switched on in the middle of an accumulation they would lack the earlier frames.
     if (p.halo && frame_index != 1u && !c->halo_complete)
@@ -1107,10 +1202,11 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     // Units without a primary ray into the root box are not traced (a scene without spheres; the counting kernels trace all)
     const bool skip_empty = mode == RT_SCENE_MESH && c->settings.bounces != 0u && !c->stats;
     if (skip_empty) { if (int rc = ensure_units(c, p, ordered)) return rc; }
-    const uint32_t n_traced_units = skip_empty ? p.n_list : p.n_units;
+    // (the number of listed units is read on the device; the host sizes the grid with it once it has arrived)
+    const uint32_t n_traced_units = skip_empty && c->units_known ? c->n_list : p.n_units;
     const bool plain_tree = skip_empty && !c->settings.anti_aliasing && !p.halo;         // (see rt_ctx::empties_settled)
     if (!plain_tree) c->unsettle();
-    const bool listed_only = plain_tree && c->empties_settled && c->image_settled[0] && frame_index != 1u && c->settled_record_ids == c->record_ids;
+    const bool listed_only = plain_tree && c->units_known && c->empties_settled && c->image_settled[0] && frame_index != 1u && c->settled_record_ids == c->record_ids;
     unsigned grid;
     if (int rc = trace_grid(c, mode, c->stats, ordered, n_traced_units * (tree ? n : 1u), grid)) return rc;
     // rt_settings.reuse_first_hits: the primary ray of a pixel and its mesh hit are the same in every Render while camera,
@@ -1132,7 +1228,8 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     const bool timed = c->timing_every != 0u && c->timing_count++ % c->timing_every == c->timing_every / 2u;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     c->tests_may_overflow = tree && !tri_tests_stay_finite(c);
-    const bool columns = tree && c->n_columns && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
+    // (until the number of column rays has arrived the pre-pass is launched as if there were some: its kernels return at once otherwise)
+    const bool columns = tree && (!c->columns_known || c->n_columns) && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
     // Which triangle a column ray hits depends on the camera, the directions, the bands and the tree only: the pre-pass runs when
     // one of those changed and its result (the best hit per column ray) is kept.  The counting kernels always run it: their
     // counters describe what the reference's walk costs for these rays.
@@ -1149,7 +1246,9 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
         q.n_frames = 1; q.first_hits = c->d_first_hits.ptr; q.first_hit_mode = 1u; q.primary_ids = nullptr;
         unsigned grid1;
         if (int rc = trace_grid(c, mode, false, ordered, n_traced_units, grid1)) return rc;
-        if (int rc = trace_and_finish_parked(c, q, mode, ordered, grid1, nullptr)) return rc;
+        bool parking1 = false;
+        if (int rc = trace_issue(c, q, mode, ordered, grid1, nullptr, parking1)) return rc;
+        if (int rc = trace_finish(c, q, mode, ordered, parking1)) return rc;
         c->first_hits_valid = true; c->view_setups++;
     }
     if (reuse) { p.first_hits = c->d_first_hits.ptr; p.first_hit_mode = 2u; }
@@ -1158,24 +1257,49 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
     p.fuse_resolve = fused ? 1u : 0u;
     if (timed) HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
-    if (int rc = trace_and_finish_parked(c, p, mode, ordered, grid, timed ? c->ev_stop[ev] : nullptr)) return rc;
-    if (timed) { c->ev_frames[ev] = n; c->ev_head++; }
-    if (skip_empty) {
-        c->host_rays += (unsigned long long)c->empty_pixels * n;
-        if (!reuse) { c->host_entry_nodes += (unsigned long long)c->entry_nodes * n; c->host_entry_tris += (unsigned long long)c->entry_tris * n; }
+    bool parking = false;
+    if (int rc = trace_issue(c, p, mode, ordered, grid, timed ? c->ev_stop[ev] : nullptr, parking)) return rc;
+    L.active = true; L.parking = parking; L.tree = tree; L.ordered = ordered; L.timed = timed; L.skip_empty = skip_empty; L.reuse = reuse;
+    L.plain_tree = plain_tree; L.listed_only = listed_only; L.fused = fused; L.mode = mode; L.ev = ev; L.gx = gx; L.gy = gy;
+    L.frame_index = frame_index; L.n = n;
+    return RT_OK;
+}
+
+// The rest of the launch: the paths it parked, the sums and the image.
+int render_finish(rt_ctx* c, rt_pending& L)
+{
+    if (!L.active) return RT_OK;
+    L.active = false;
+    RtParams& p = L.p;
+    const uint32_t n = L.n, frame_index = L.frame_index;
+    if (int rc = trace_finish(c, p, L.mode, L.ordered, L.parking)) return rc;
+    if (L.timed) { c->ev_frames[L.ev] = n; c->ev_head++; }
+    if (L.skip_empty) {
+        c->view_age++;
+        c->owed_unit_frames += n;
+        if (!L.reuse && p.unit_entry) c->owed_entry_frames += n;
     }
     const uint32_t frame_last = frame_index + n - 1u;
     c->latest_in_back = false;
-    if (tree) {
-        LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, (c->settings.anti_aliasing ? 0 : 1) | (listed_only ? 2 : 0), c->stream));
+    if (L.tree) {
+        LAUNCH_TRY(c, rt_launch_sum_resolve(&p, frame_last, (c->settings.anti_aliasing ? 0 : 1) | (L.listed_only ? 2 : 0), c->stream));
         c->heads_zero = true;
         // a pass over every unit leaves the units without a path with their sum of +0, their ids and, in the buffer it wrote, their image
-        if (plain_tree && frame_index == 1u) c->empties_settled = true;
-        if (plain_tree && c->empties_settled && !listed_only) { c->image_settled[0] = true; c->settled_record_ids = c->record_ids; }
+        if (L.plain_tree && frame_index == 1u) c->empties_settled = true;
+        if (L.plain_tree && c->empties_settled && !L.listed_only) { c->image_settled[0] = true; c->settled_record_ids = c->record_ids; }
     }
-    else if (!fused) LAUNCH_TRY(c, rt_launch_resolve(&p, frame_last, gx, gy, c->stream));
-    if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_last, gx, gy, c->stream));
+    else if (!L.fused) LAUNCH_TRY(c, rt_launch_resolve(&p, frame_last, L.gx, L.gy, c->stream));
+    if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_last, L.gx, L.gy, c->stream));
     return RT_OK;
+}
+
+// What every Render call checks first.
+int render_checks(rt_ctx* c, uint32_t frame_index, uint32_t n)
+{
+    if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
+    if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
+    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render before rt_set_camera (the camera position is needed even with rt_set_ray_dirs)");
+    return validate_scene(c, c->settings.scene_mode);
 }
 
 }  // namespace
@@ -1183,18 +1307,16 @@ int render_launch(rt_ctx* c, uint32_t frame_index, uint32_t n)
 int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
 {
     if (!c) return RT_E_ARG;
-    if (!frame_index || !n || frame_index + n < frame_index) return fail(c, RT_E_ARG, "rt_render: frame_index %u, n %u", frame_index, n);
-    if (!c->width) return fail(c, RT_E_STATE, "rt_render before rt_resize");
-    if (!c->have_camera) return fail(c, RT_E_STATE, "rt_render before rt_set_camera (the camera position is needed even with rt_set_ray_dirs)");
-    const int mode = c->settings.scene_mode;
-    if (int rc = validate_scene(c, mode)) return rc;
+    if (int rc = render_checks(c, frame_index, n)) return rc;
     DeviceGuard g(c->device);
     if (int rc = collect_time(c, false)) return rc;
     // sphere scenes: a lane keeps its pixel for all n frames, whatever n; tree scenes: at most RT_MAX_LAUNCH_FRAMES planes of slots
-    const uint32_t per_launch = mode == RT_SCENE_SPHERES ? n : (uint32_t)RT_MAX_LAUNCH_FRAMES;
+    const uint32_t per_launch = c->settings.scene_mode == RT_SCENE_SPHERES ? n : (uint32_t)RT_MAX_LAUNCH_FRAMES;
+    rt_pending L;
     for (uint32_t done = 0; done < n; done += per_launch) {
         const uint32_t k = n - done < per_launch ? n - done : per_launch;
-        if (int rc = render_launch(c, frame_index + done, k)) return rc;
+        if (int rc = render_issue(c, frame_index + done, k, L)) return rc;
+        if (int rc = render_finish(c, L)) return rc;
     }
     return RT_OK;
 }
@@ -1366,6 +1488,7 @@ int rt_read_counters(rt_ctx* c, rt_counters* out)
     std::vector<unsigned long long> h(c->d_counters.count);
     HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_counters.ptr, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     if (int rc = rt_sync(c)) return rc;
+    if (int rc = settle_view(c, true)) return rc;
     for (size_t i = 0; i < h.size(); i += 4) {
         out->rays += h[i]; out->nodes_visited += h[i + 1]; out->tris_tested += h[i + 2]; out->sphere_tests += h[i + 3];
     }
@@ -1386,7 +1509,7 @@ int rt_reset_counters(rt_ctx* c)
     DeviceGuard g(c->device);
     HIP_TRY(c, hipMemsetAsync(c->d_counters.ptr, 0, c->d_counters.count * sizeof(unsigned long long), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_column_stats.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
-    c->host_rays = 0; c->view_setups = 0; c->host_entry_nodes = 0; c->host_entry_tris = 0;
+    c->host_rays = 0; c->view_setups = 0; c->host_entry_nodes = 0; c->host_entry_tris = 0; c->owed_unit_frames = 0; c->owed_entry_frames = 0;
     return RT_OK;
 }
 
@@ -1431,6 +1554,30 @@ int rt_reset_kernel_time(rt_ctx* c)
 }
 
 // ---- for rt_group.hip (not part of the C ABI) ----
+// One launch of rt_render_frames in two halves, so that a group can issue on every context before it finishes any.
+// rt_internal_launch_frames: the Renders one launch of this context holds at most (0 = any number).
+__attribute__((visibility("hidden"))) uint32_t rt_internal_launch_frames(const rt_ctx* c) { return c->settings.scene_mode == RT_SCENE_SPHERES ? 0u : (uint32_t)RT_MAX_LAUNCH_FRAMES; }
+__attribute__((visibility("hidden"))) rt_pending* rt_internal_pending_new() { return new rt_pending(); }
+__attribute__((visibility("hidden"))) void rt_internal_pending_free(rt_pending* L) { delete L; }
+__attribute__((visibility("hidden"))) int rt_internal_render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending* L)
+{
+    if (int rc = render_checks(c, frame_index, n)) return rc;
+    DeviceGuard g(c->device);
+    if (int rc = collect_time(c, false)) return rc;
+    return render_issue(c, frame_index, n, *L);
+}
+__attribute__((visibility("hidden"))) int rt_internal_render_finish(rt_ctx* c, rt_pending* L)
+{
+    DeviceGuard g(c->device);
+    return render_finish(c, *L);
+}
+// 1: the issued launch parks paths and its main trace kernel has not finished yet; 0: it has, or the launch needs no word back.
+__attribute__((visibility("hidden"))) int rt_internal_issue_in_flight(rt_ctx* c, const rt_pending* L)
+{
+    if (!L->active || !L->parking) return 0;
+    DeviceGuard g(c->device);
+    return hipEventQuery(c->parked_ready) == hipErrorNotReady ? 1 : 0;
+}
 __attribute__((visibility("hidden"))) hipStream_t rt_internal_stream(rt_ctx* c) { return c->stream; }
 __attribute__((visibility("hidden"))) int rt_internal_device(const rt_ctx* c) { return c->device; }
 __attribute__((visibility("hidden"))) void rt_internal_size(const rt_ctx* c, uint32_t* w, uint32_t* h) { *w = c->width; *h = c->height; }

@@ -152,10 +152,15 @@ struct RtParams {
     // kernel then draws its tickets over unit_list (the n_list other units, ascending) and the resolve pass takes a radiance of
     // zero for the units marked in unit_empty.  unit_*_out: where the classification writes (unit_empty, list, counts = {n_list,
     // pixels of empty units, node steps and triangle tests that unit_entry spares the primary walks of one Render}).
+    // The host launches all of this without waiting for any of it: the trace kernel and the entry kernel read the length of the list
+    // from unit_counts[0] on the device; n_list is the host's copy, zero until it has arrived (only the resolve pass over the listed
+    // units, which runs from the second Render of an accumulation on, needs it on the host).
     const uint32_t* unit_list;
     uint32_t n_list;
+    const uint32_t* unit_counts;
     const unsigned char* unit_empty;
     unsigned char* unit_empty_out; uint32_t* unit_list_out; uint32_t* unit_counts_out;
+    uint32_t* unit_block_out;               // scratch: per 64 units, listed units | pixels of empty units << 8; then the listed units before them
     // ... and where the walk of a primary ray may start.  The sixteen primary rays of a unit make the same decisions at the first
     // nodes of their walk (same origin, neighbouring directions): unit_entry[pixel] is the first node at which they do not --
     // a box some enter and some miss, or a leaf in which one of them hits a triangle.  Up to there no ray of the unit has hit
@@ -184,7 +189,7 @@ struct RtParams {
     uint32_t  column_queue_cap;
     unsigned long long* column_best;         // per slot: bits(t) << 32 | leaf record index of the closest hit, ~0 = miss
     uint32_t* column_flags;                  // bit 0: the pre-pass result may not be used (a decision depended on t, or the queue overflowed)
-    unsigned char* reached;                  // per node: visited by column rays (pre-pass scratch)
+    unsigned long long* reached;             // one bit per node (bit j & 63 of word j >> 6): a leaf-bearing box the rays of the family enter (pre-pass scratch)
     const uint32_t* rec_leaf;                // per leaf record: node index of its leaf (what leafrecs[3 r + 2].z holds, packed: the kernels that
                                              // stream over all records look here first and read only the records of visited leaves)
     // Bounce rays with direction.x == 0 in a large tree ("parked" paths): the trace kernel stores the path and frees the lane,

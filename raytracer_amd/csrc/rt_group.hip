@@ -25,6 +25,13 @@ extern "C" int rt_internal_device(const rt_ctx*);
 extern "C" void rt_internal_size(const rt_ctx*, uint32_t* w, uint32_t* h);
 extern "C" int rt_internal_resolve_from(rt_ctx*, const void* accum_float4, uint32_t frame_index);
 extern "C" void rt_internal_set_error(const char* msg);
+struct rt_pending;
+extern "C" uint32_t rt_internal_launch_frames(const rt_ctx*);
+extern "C" rt_pending* rt_internal_pending_new();
+extern "C" void rt_internal_pending_free(rt_pending*);
+extern "C" int rt_internal_render_issue(rt_ctx*, uint32_t frame_index, uint32_t n, rt_pending*);
+extern "C" int rt_internal_render_finish(rt_ctx*, rt_pending*);
+extern "C" int rt_internal_issue_in_flight(rt_ctx*, const rt_pending*);
 
 namespace {
 
@@ -74,6 +81,8 @@ struct DeviceGuard {
 struct rt_group {
     std::vector<rt_ctx*> ctx;
     std::vector<hipEvent_t> pushed;          // per context: its push into GPU 0's memory has finished
+    std::vector<rt_pending*> pending;        // per context: the launch that has been issued and not finished
+    int issue_overlap = -1;                  // see rt_group_issue_overlap
     std::string error;
     float* d_parts = nullptr;                // on GPU 0: (n - 1) x width*height x 3 sums pushed by the other contexts
     float4* d_sum = nullptr;                 // on GPU 0: the sum over all contexts (what the displayed frame is resolved from)
@@ -110,6 +119,39 @@ int set_banding(rt_group* g, bool on)
     return RT_OK;
 }
 
+// Renders first .. first + n - 1 (context i: first_of(i)) on every context: the trace launch of each is issued before the host
+// waits for any of them -- for the word a launch parks paths under (trees large enough for that), which decides what follows
+// it -- so the GPUs of a group trace side by side, as the rows of Renderer::Render run side by side and are joined at the end
+// (Renderer.cpp:59-81).  Tree scenes take launches of up to 16 Renders: each such round is issued everywhere, then finished.
+template <class FirstOf>
+int render_everywhere(rt_group* g, uint32_t n, FirstOf first_of, const char* what)
+{
+    const uint32_t ctxs = (uint32_t)g->ctx.size();
+    uint32_t per_launch = rt_internal_launch_frames(g->ctx[0]);
+    if (!per_launch || per_launch > n) per_launch = n;
+    g->issue_overlap = 0;
+    for (uint32_t done = 0; done < n; done += per_launch) {
+        const uint32_t k = n - done < per_launch ? n - done : per_launch;
+        int rc = RT_OK, failed = -1;
+        for (uint32_t i = 0; i < ctxs && rc == RT_OK; ++i) {
+            rc = rt_internal_render_issue(g->ctx[i], first_of(i) + done, k, g->pending[i]);
+            if (rc != RT_OK) failed = (int)i;
+        }
+        if (rc == RT_OK && done == 0) {
+            int in_flight = 0;
+            for (uint32_t i = 0; i < ctxs; ++i) in_flight += rt_internal_issue_in_flight(g->ctx[i], g->pending[i]);
+            g->issue_overlap = in_flight;
+        }
+        // (what was issued is finished even after a failure elsewhere: a launch must not be left without its resolve pass)
+        for (uint32_t i = 0; i < ctxs; ++i) {
+            const int rf = rt_internal_render_finish(g->ctx[i], g->pending[i]);
+            if (rf != RT_OK && rc == RT_OK) { rc = rf; failed = (int)i; }
+        }
+        if (rc != RT_OK) return ctx_fail(g, failed, rc, what);
+    }
+    return RT_OK;
+}
+
 unsigned copy_grid(size_t n) { const size_t b = (n + 255) / 256; return (unsigned)(b < 8192 ? (b ? b : 1) : 8192); }
 
 }  // namespace
@@ -124,6 +166,7 @@ rt_group* rt_group_create(const int* device_ids, int n_devices)
         rt_ctx* c = rt_create(device_ids[i]);
         if (!c) { rt_group_destroy(g); return nullptr; }                     // rt_last_error(NULL) holds rt_create's message
         g->ctx.push_back(c);
+        g->pending.push_back(rt_internal_pending_new());
         hipEvent_t ev = nullptr;
         DeviceGuard dg(device_ids[i]);
         if (!dg.ok || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -166,6 +209,7 @@ void rt_group_destroy(rt_group* g)
         if (i < g->pushed.size() && g->pushed[i]) { DeviceGuard dg(rt_internal_device(g->ctx[i])); (void)hipEventDestroy(g->pushed[i]); }
         rt_destroy(g->ctx[i]);
     }
+    for (rt_pending* L : g->pending) rt_internal_pending_free(L);
     delete g;
 }
 
@@ -185,9 +229,9 @@ int rt_group_render_tiles(rt_group* g, uint32_t frame_index, uint32_t n_frames)
         rt_internal_size(g->ctx[i], &wi, &hi);
         if (wi != w || hi != h || !w) return gfail(g, RT_E_STATE, "rt_group_render_tiles: context %u is %ux%u, context 0 %ux%u (rt_resize all of them alike)", i, wi, hi, w, h);
     }
-    // every GPU starts on its bands before any push is queued: the launches are asynchronous, so the GPUs trace side by side
-    for (uint32_t i = 0; i < n; ++i)
-        if (int rc = rt_render_frames(g->ctx[i], frame_index, n_frames)) return ctx_fail(g, (int)i, rc, "rt_render_frames");
+    // every GPU is at work on its bands before the host waits for any of them, and before any push is queued
+    if (!n_frames) return gfail(g, RT_E_ARG, "rt_group_render_tiles: no frames");
+    if (int rc = render_everywhere(g, n_frames, [&](uint32_t) { return frame_index; }, "rt_render_frames")) return rc;
     float4* const frame0 = static_cast<float4*>(rt_device_image(g->ctx[0]));
     const uint32_t bands = (h + RT_TILE - 1) / RT_TILE;
     for (uint32_t i = 1; i < n; ++i) {
@@ -236,10 +280,9 @@ int rt_group_render_samples(rt_group* g, uint32_t frame_first, uint32_t frames_p
     }
     // context i renders the frame indices frame_first + i * frames_per_ctx ... of this call; a new accumulation (frame_first
     // == 1) starts every context from zero (context 0 by its frame index 1, Renderer.cpp:55-56, the others explicitly)
-    for (uint32_t i = 0; i < n; ++i) {
-        if (frame_first == 1u && i != 0u) { if (int rc = rt_reset_accum(g->ctx[i])) return ctx_fail(g, (int)i, rc, "rt_reset_accum"); }
-        if (int rc = rt_render_frames(g->ctx[i], frame_first + i * frames_per_ctx, frames_per_ctx)) return ctx_fail(g, (int)i, rc, "rt_render_frames");
-    }
+    for (uint32_t i = 1; i < n; ++i)
+        if (frame_first == 1u) { if (int rc = rt_reset_accum(g->ctx[i])) return ctx_fail(g, (int)i, rc, "rt_reset_accum"); }
+    if (int rc = render_everywhere(g, frames_per_ctx, [&](uint32_t i) { return frame_first + i * frames_per_ctx; }, "rt_render_frames")) return rc;
     for (uint32_t i = 1; i < n; ++i) {
         DeviceGuard dg(rt_internal_device(g->ctx[i]));
         hipStream_t s = rt_internal_stream(g->ctx[i]);
@@ -263,6 +306,8 @@ int rt_group_render_samples(rt_group* g, uint32_t frame_first, uint32_t frames_p
     if (int rc = rt_internal_resolve_from(g->ctx[0], g->d_sum, frame_first + n * frames_per_ctx - 1u)) return ctx_fail(g, 0, rc, "resolve");
     return RT_OK;
 }
+
+int rt_group_issue_overlap(const rt_group* g) { return g ? g->issue_overlap : -1; }
 
 int rt_group_read_accum(rt_group* g, float* out_rgb)
 {

@@ -1067,26 +1067,44 @@ __global__ __launch_bounds__(256) void rt_column_assign_kernel(RtParams p)
 
 // Boxes of the directions of 16, 64 and 256 consecutive slots: { min dy, max dy, min dz, max dz }.  A box holding a
 // non-finite or huge component must not be used for the proof: it is stored with dy_lo = NaN, which the filter checks first.
+// One workgroup per 256 slots, one lane per slot: minima and maxima by butterfly exchanges over 16 and 64 lanes, the four
+// waves' boxes combined through LDS.  (One thread per box, reading up to 256 directions one after the other, took 44 us.)
 __global__ __launch_bounds__(256) void rt_column_chunks_kernel(RtParams p)
 {
+    __shared__ float4 wave_box[4];
+    __shared__ int wave_ok[4];
     const uint32_t count = *p.column_count < p.column_cap ? *p.column_count : p.column_cap;
-    const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    uint32_t first, last; float4* out;
-    if (i < n16) { first = i * 16u; last = first + 16u; out = p.column_box16 + i; }
-    else if (i < n16 + n64) { first = (i - n16) * 64u; last = first + 64u; out = p.column_box64 + (i - n16); }
-    else if (i < n16 + n64 + n256) { first = (i - n16 - n64) * 256u; last = first + 256u; out = p.column_box256 + (i - n16 - n64); }
-    else return;
-    if (last > count) last = count;
-    float ylo = __builtin_inff(), yhi = -__builtin_inff(), zlo = ylo, zhi = yhi;
-    bool usable = true;
-    for (uint32_t k = first; k < last; ++k) {
+    if (blockIdx.x * 256u >= count) return;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const bool have = k < count;
+    const float inf = __builtin_inff();
+    float ylo = inf, yhi = -inf, zlo = inf, zhi = -inf;
+    int ok = 1;
+    if (have) {
         const float4 d = p.column_dirs[k];
-        usable = usable && (fabsf(d.y) < 1e9f) && (fabsf(d.z) < 1e9f);      // false for NaN and infinities too
-        ylo = (d.y < ylo) ? d.y : ylo; yhi = (d.y > yhi) ? d.y : yhi;
-        zlo = (d.z < zlo) ? d.z : zlo; zhi = (d.z > zhi) ? d.z : zhi;
+        ok = (fabsf(d.y) < 1e9f && fabsf(d.z) < 1e9f) ? 1 : 0;                 // false for NaN and infinities too
+        ylo = yhi = d.y; zlo = zhi = d.z;
     }
-    *out = usable ? make_float4(ylo, yhi, zlo, zhi) : make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f);
+    auto combine = [&](int off) {
+        const float a = __shfl_xor(ylo, off), b = __shfl_xor(yhi, off), c = __shfl_xor(zlo, off), d = __shfl_xor(zhi, off);
+        ylo = (a < ylo) ? a : ylo; yhi = (b > yhi) ? b : yhi; zlo = (c < zlo) ? c : zlo; zhi = (d > zhi) ? d : zhi;
+        ok &= __shfl_xor(ok, off);
+    };
+    auto box = [&]() { return ok ? make_float4(ylo, yhi, zlo, zhi) : make_float4(__builtin_nanf(""), 0.0f, 0.0f, 0.0f); };
+    combine(1); combine(2); combine(4); combine(8);
+    if ((lane & 15u) == 0u && have) p.column_box16[k >> 4] = box();
+    combine(16); combine(32);
+    if (lane == 0u && have) p.column_box64[k >> 6] = box();
+    if (lane == 0u) { wave_box[wv] = make_float4(ylo, yhi, zlo, zhi); wave_ok[wv] = ok; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (uint32_t w = 1; w < 4u; ++w) {
+            const float4 o = wave_box[w];
+            ylo = (o.x < ylo) ? o.x : ylo; yhi = (o.y > yhi) ? o.y : yhi; zlo = (o.z < zlo) ? o.z : zlo; zhi = (o.w > zhi) ? o.w : zhi;
+            ok &= wave_ok[w];
+        }
+        p.column_box256[blockIdx.x] = box();
+    }
 }
 
 // -- per frame --
@@ -1211,7 +1229,9 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     if (lane == 0u) excl = 0u;
     const uint32_t limit = excl > before ? excl : before;
     const bool visited = j < p.n_nodes && j >= limit;
-    if (j < p.n_nodes) p.reached[j] = (visited && box) ? 1 : 0;
+    // (one bit per node, a word per wave: a byte store per lane made this kernel ten times as long as the pass before it)
+    const unsigned long long entered = __ballot(visited && box);
+    if (lane == 0u && (j & ~63u) < p.n_nodes) p.reached[j >> 6] = entered;
     // a visited box with a real t_near could be pruned by the closest t so far: then the visited set is not fixed
     if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.ray_slot < 0 ? p.column_flags : (uint32_t*)p.park_info + 2 * RT_PARK_FAMILIES + p.ray_slot, 1u);
     if (stats) {
@@ -1363,6 +1383,22 @@ __device__ __forceinline__ bool park_box_rejects(F3 v0, F3 e1, F3 e2, float ox, 
     return !(t.hi > 0.00001f);
 }
 
+// Every ray of a family (the column rays, or parked rays with one origin.x) lies in the plane x = origin.x (direction.x is a
+// zero), and a hit needs u, v >= 0, u + v <= 1 with, in exact arithmetic, u e1.x + v e2.x = origin.x - v0.x: the plane has to
+// cross the triangle.  The computed u and v miss the exact ones by at most (7 u_r (S_u |e1.x| + S_v |e2.x|) + 5 u_r |s.x| A) / |a|
+// in that combination (u_r = 2^-24; A, S_u, S_v the sums of the absolute values of the terms of the determinant and the two
+// numerators), |a| >= 1e-5 or the test rejects anyway, and A <= 2 d |e1|_1 |e2|_1, S_u, S_v <= 2 d |s|_inf |e|_1 with d = max
+// |direction component|: so a triangle whose x extent stays clear of the plane by more than 2 * 38 u_r d |s|_inf |e1|_1 |e2|_1 / 1e-5
+// (twice the first-order bound) fails the test for every ray of the family.  That is all but the few rows of triangles along
+// the plane.  sx = origin.x - v0.x; s_inf, d: bounds of |origin - v0| and of the direction components over the family (d >= 1).
+__device__ __forceinline__ bool clear_of_the_rays_plane(F3 e1, F3 e2, float sx, float s_inf, float d)
+{
+    const float n1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z), n2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+    const float clear = (76.0f * 5.9604645e-8f * 1e5f) * d * s_inf * n1 * n2 + 4.0f * 5.9604645e-8f * ((fabsf(e1.x) + fabsf(e2.x)) + fabsf(sx));
+    const float xlo = fminf(0.0f, fminf(e1.x, e2.x)), xhi = fmaxf(0.0f, fmaxf(e1.x, e2.x));
+    return sx < xlo - clear || sx > xhi + clear;
+}
+
 // One lane per leaf record of a leaf the family visits: boxes of 256, then 64, then 16 of the family's rays; the (record, 16 rays)
 // pairs that cannot be proven misses go to the family's queue.
 __global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int stats)
@@ -1373,7 +1409,7 @@ __global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int sta
     if (p.park_info[2 * RT_PARK_FAMILIES + fam] & 1) return;           // the visited set is not fixed: the test kernel flags the rays
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     bool use = false;
-    if (r < p.n_refs) use = p.reached[p.rec_leaf[r]] != 0;
+    if (r < p.n_refs) { const uint32_t leaf = p.rec_leaf[r]; use = ((p.reached[leaf >> 6] >> (leaf & 63u)) & 1ull) != 0ull; }
     if (stats) {
         const uint32_t n = (uint32_t)__popcll(__ballot(use));
         if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * count);       // the tests the reference makes
@@ -1389,13 +1425,7 @@ __global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int sta
     const float4* box256 = box64 + 2u * (RT_PARK_SLOTS / 64u);
     const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
     uint2* queue = p.park_queue + (size_t)fam * p.park_queue_cap;
-    // Every ray of the family lies in the plane x = origin.x (direction.x is a zero), and a hit needs u, v >= 0, u + v <= 1 with,
-    // in exact arithmetic, u e1.x + v e2.x = origin.x - v0.x: the plane has to cross the triangle.  The computed u and v miss
-    // the exact ones by at most (7 u_r (S_u |e1.x| + S_v |e2.x|) + 5 u_r |s.x| A) / |a| in that combination (u_r = 2^-24; A, S_u, S_v
-    // the sums of the absolute values of the terms of the determinant and the two numerators), |a| >= 1e-5 or the test rejects
-    // anyway, and A <= 2 d |e1|_1 |e2|_1, S_u, S_v <= 2 d |s|_inf |e|_1 with d = max |direction component|: so a triangle whose
-    // x extent stays clear of the plane by more than 2 * 38 u_r d |s|_inf |e1|_1 |e2|_1 / 1e-5 (twice the first-order bound)
-    // fails the test for every ray of the family.  That is all but the few rows of triangles along the plane.
+    // the plane of the family's rays has to cross the triangle (see clear_of_the_rays_plane)
     {
         const float4 f0 = box16[2u * RT_PARK_BOXES], f1 = box16[2u * RT_PARK_BOXES + 1u];
         if (tame && f0.x == f0.x) {
@@ -1403,10 +1433,7 @@ __global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int sta
             const float sy = fmaxf(fabsf(f0.x - v0.y), fabsf(f0.y - v0.y)), sz = fmaxf(fabsf(f0.z - v0.z), fabsf(f0.w - v0.z));
             const float s_inf = fmaxf(fabsf(sx), fmaxf(sy, sz));
             const float d = fmaxf(1.0f, fmaxf(fmaxf(fabsf(f1.x), fabsf(f1.y)), fmaxf(fabsf(f1.z), fabsf(f1.w))));
-            const float n1 = (fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z), n2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
-            const float clear = (76.0f * 5.9604645e-8f * 1e5f) * d * s_inf * n1 * n2 + 4.0f * 5.9604645e-8f * ((fabsf(e1.x) + fabsf(e2.x)) + fabsf(sx));
-            const float xlo = fminf(0.0f, fminf(e1.x, e2.x)), xhi = fmaxf(0.0f, fmaxf(e1.x, e2.x));
-            if (sx < xlo - clear || sx > xhi + clear) return;
+            if (clear_of_the_rays_plane(e1, e2, sx, s_inf, d)) return;
         }
     }
     for (uint32_t c256 = 0; c256 < n256; ++c256) {
@@ -1477,7 +1504,8 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
     bool use = false;
     float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
     if (r < p.n_refs) {
-        use = p.reached[p.rec_leaf[r]] != 0;
+        const uint32_t leaf = p.rec_leaf[r];
+        use = ((p.reached[leaf >> 6] >> (leaf & 63u)) & 1ull) != 0ull;
         if (use) { r0 = p.leafrecs[3 * (size_t)r]; r1 = p.leafrecs[3 * (size_t)r + 1]; r2 = p.leafrecs[3 * (size_t)r + 2]; }
     }
     const unsigned long long any = __ballot(use);
@@ -1493,6 +1521,18 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
     const bool tame = fabsf(c.s.x) < big && fabsf(c.s.y) < big && fabsf(c.s.z) < big && fabsf(c.e1.x) < big && fabsf(c.e1.y) < big &&
                       fabsf(c.e1.z) < big && fabsf(c.e2.x) < big && fabsf(c.e2.y) < big && fabsf(c.e2.z) < big;
     const uint32_t n16 = (count + 15u) / 16u, n64 = (count + 63u) / 64u, n256 = (count + 255u) / 256u;
+    // All column rays start at the camera and have direction.x == +0: the plane x = camera.x has to cross the triangle (see
+    // clear_of_the_rays_plane; the largest direction component comes from the boxes of 256 rays, a few wave-uniform reads).
+    if (tame) {
+        float d = 1.0f;
+        bool usable = true;
+        for (uint32_t c256 = 0; c256 < n256; ++c256) {
+            const float4 b = p.column_box256[c256];
+            usable = usable && b.x == b.x;
+            d = fmaxf(d, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+        }
+        if (usable && clear_of_the_rays_plane(c.e1, c.e2, c.s.x, fmaxf(fabsf(c.s.x), fmaxf(fabsf(c.s.y), fabsf(c.s.z))), d)) return;
+    }
     for (uint32_t c256 = 0; c256 < n256; ++c256) {
         const float4 b256 = p.column_box256[c256];
         if (tame && b256.x == b256.x && column_box_rejects(c, b256)) continue;
@@ -1565,10 +1605,10 @@ __global__ __launch_bounds__(256) void rt_column_exact_kernel(RtParams p)
 // A launch of n_frames Renders hands out (unit, frame) pairs: head h owns units h, h + 8, ... and its ticket t is frame t % n_frames
 // of unit h + 8 (t / n_frames), so the tickets of one refill are consecutive frames of the same pixels: their primary rays are
 // the same ray and walk the same nodes side by side.
-__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h)
+// n_work: the units there are to draw (the length of unit_list, read from the device once per wave, or n_units)
+__device__ __forceinline__ uint32_t head_count(const RtParams& p, uint32_t h, uint32_t n_work)
 {
-    const uint32_t n = p.unit_list ? p.n_list : p.n_units;
-    return ((n + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS) * p.n_frames;
+    return ((n_work + RT_WORK_HEADS - 1u - h) / RT_WORK_HEADS) * p.n_frames;
 }
 __device__ __forceinline__ uint32_t head_unit(const RtParams& p, uint32_t h, uint32_t t)
 {
@@ -1815,6 +1855,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     F3 winvD = f3(0.0f, 0.0f, 0.0f);
     uint32_t woct = 0;                                      // which of the eight node arrays the walk reads (0 = the reference's preorder)
     const uint32_t end = p.n_nodes;
+    const uint32_t n_work = p.unit_list ? (uint32_t)__builtin_amdgcn_readfirstlane((int)p.unit_counts[0]) : p.n_units;
 
     // the whole state of this lane's path to / from slot `slot` of the pool
     auto path_transfer = [&](const bool save, const uint32_t slot) {
@@ -1873,7 +1914,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
         unsigned long long need = __ballot(phase == PH_IDLE);
         uint32_t want = (uint32_t)__popcll(need) / RT_UNIT;
         while (want != 0u && heads_empty < RT_WORK_HEADS) {
-            const uint32_t count = head_count(p, head);
+            const uint32_t count = head_count(p, head, n_work);
             uint32_t t = 0;
             if (lane == 0) t = atomicAdd(p.work_heads + head * RT_HEAD_STRIDE, want);
             t = __builtin_amdgcn_readfirstlane(t);
@@ -2286,9 +2327,13 @@ __global__ __launch_bounds__(256) void rt_sum_resolve_kernel(RtParams p, uint32_
 // Which work units are empty (RtParams::unit_list): sixteen lanes per unit, one per pixel.  A unit is empty when every pixel of
 // it that lies in the frame has a primary ray with direction.x != 0 (the others take the column pre-pass) that fails the root
 // node's test exactly as the walk's first step would (slab_test, "descend" in tree_body).
-__global__ __launch_bounds__(256) void rt_units_classify_kernel(RtParams p)
+// A workgroup of 1024 threads classifies 64 units and leaves one word for the scan that follows: the units it found to list in
+// the low byte, above it the pixels of its empty units.  (One atomic per empty unit onto a single counter, as this kernel had it,
+// took a millisecond of a 4K frame's classification: 370,000 atomics on one address.)
+__global__ __launch_bounds__(1024) void rt_units_classify_kernel(RtParams p)
 {
-    const uint32_t unit = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t unit = blockIdx.x * (1024u / RT_UNIT) + threadIdx.x / RT_UNIT;
     uint32_t pixel = 0;
     const bool in_frame = unit < p.n_units && unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel);
     bool live = false;                                      // this pixel's primary ray has to be traced
@@ -2298,15 +2343,56 @@ __global__ __launch_bounds__(256) void rt_units_classify_kernel(RtParams p)
         live = d.x == 0.0f || (slab_test(p.nodes[0], p.nodes[1], f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]),
                                          f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z), tNear) && !(tNear > FLT_MAX));
     }
-    const uint32_t group = (threadIdx.x & 63u) / RT_UNIT;
-    const unsigned long long mask = 0xFFFFull << (RT_UNIT * group);
+    const uint32_t lane = threadIdx.x & 63u, group = lane / RT_UNIT;
     static_assert(RT_UNIT == 16, "sixteen lanes per unit");
-    const bool empty = (__ballot(live) & mask) == 0ull;
-    const uint32_t pixels = (uint32_t)__popcll(__ballot(in_frame) & mask);
-    if (unit < p.n_units && threadIdx.x % RT_UNIT == 0u) {
-        p.unit_empty_out[unit] = empty ? 1 : 0;
-        if (empty && pixels) atomicAdd(p.unit_counts_out + 1, pixels);
+    const unsigned long long lives = __ballot(live), frames = __ballot(in_frame);
+    uint32_t word = 0;                                      // this wave's four units: listed | pixels of the empty ones << 8
+    for (uint32_t g = 0; g < 4u; ++g) {
+        const bool exists = blockIdx.x * (1024u / RT_UNIT) + (threadIdx.x >> 6) * 4u + g < p.n_units;
+        const bool empty = ((lives >> (RT_UNIT * g)) & 0xFFFFull) == 0ull;
+        if (exists) word += empty ? (uint32_t)__popcll((frames >> (RT_UNIT * g)) & 0xFFFFull) << 8 : 1u;
     }
+    if (unit < p.n_units && threadIdx.x % RT_UNIT == 0u) p.unit_empty_out[unit] = ((lives >> (RT_UNIT * group)) & 0xFFFFull) == 0ull ? 1 : 0;
+    if (lane == 0u) wave_sum[threadIdx.x >> 6] = word;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t sum = 0;
+        for (uint32_t w = 0; w < 16u; ++w) sum += wave_sum[w];
+        p.unit_block_out[blockIdx.x] = sum;
+    }
+}
+
+// One workgroup: the listed units before each group of 64 (an exclusive prefix sum over the words of the kernel above, in
+// place), their total and the pixels of all empty units into unit_counts[0 .. 1]; the two counters of the entry kernel start at zero.
+__global__ __launch_bounds__(1024) void rt_units_scan_kernel(RtParams p, uint32_t n_blocks)
+{
+    __shared__ uint32_t part[1024], pix[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = tid * per < n_blocks ? tid * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    uint32_t sum = 0, pixels = 0;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.unit_block_out[i]; sum += v & 0xFFu; pixels += v >> 8; }
+    part[tid] = sum; pix[tid] = pixels;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024u; off <<= 1) {               // Hillis-Steele inclusive scan (the pixel counts only need their total)
+        const uint32_t v = tid >= off ? part[tid - off] : 0u, w = tid >= off ? pix[tid - off] : 0u;
+        __syncthreads();
+        part[tid] += v; pix[tid] += w;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = p.unit_block_out[i] & 0xFFu; p.unit_block_out[i] = run; run += v; }
+    if (tid == 1023u) { p.unit_counts_out[0] = part[1023]; p.unit_counts_out[1] = pix[1023]; p.unit_counts_out[2] = 0u; p.unit_counts_out[3] = 0u; }
+}
+
+// The listed units in ascending order: one wave per group of 64 units, one lane per unit.
+__global__ __launch_bounds__(256) void rt_units_assign_kernel(RtParams p)
+{
+    const uint32_t group64 = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t unit = group64 * 64u + lane;
+    const bool listed = unit < p.n_units && p.unit_empty_out[unit] == 0;
+    const unsigned long long m = __ballot(listed);
+    if (listed) p.unit_list_out[p.unit_block_out[group64] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = unit;
 }
 
 // Where the walks of a listed unit's primary rays may start (RtParams::unit_entry): sixteen lanes per unit walk in step, with the
@@ -2314,8 +2400,9 @@ __global__ __launch_bounds__(256) void rt_units_classify_kernel(RtParams p)
 // of them hits a triangle.  Rays with direction.x == 0 do not walk (pre-pass) and have no say.
 __global__ __launch_bounds__(256) void rt_units_entry_kernel(RtParams p)
 {
+    __shared__ uint32_t wave_nodes[4], wave_tris[4];
     const uint32_t li = blockIdx.x * (256u / RT_UNIT) + threadIdx.x / RT_UNIT;
-    const bool listed = li < p.n_list;
+    const bool listed = li < p.unit_counts_out[0];           // (the grid covers every unit there could be)
     const uint32_t unit = listed ? p.unit_list_out[li] : 0u;
     uint32_t pixel = 0;
     const bool in_frame = listed && unit_pixel(p, unit, threadIdx.x % RT_UNIT, pixel);
@@ -2367,30 +2454,13 @@ __global__ __launch_bounds__(256) void rt_units_entry_kernel(RtParams p)
     if (in_frame) p.unit_entry_out[pixel] = cursor;
     if (!live) { n_nodes = 0; n_tris = 0; }
     for (int off = 32; off > 0; off >>= 1) { n_nodes += __shfl_down(n_nodes, off); n_tris += __shfl_down(n_tris, off); }
-    if ((threadIdx.x & 63u) == 0u) {
-        atomicAdd(p.unit_counts_out + 2, n_nodes);
-        atomicAdd(p.unit_counts_out + 3, n_tris);
-    }
-}
-
-// The other units, in ascending order: one workgroup, every thread a contiguous share.
-__global__ __launch_bounds__(1024) void rt_units_compact_kernel(RtParams p)
-{
-    __shared__ uint32_t part[1024];
-    const uint32_t share = (p.n_units + 1023u) / 1024u;
-    const uint32_t lo = threadIdx.x * share, hi = lo + share < p.n_units ? lo + share : p.n_units;
-    uint32_t n = 0;
-    for (uint32_t u = lo; u < hi; ++u) n += p.unit_empty_out[u] ? 0u : 1u;
-    part[threadIdx.x] = n;
+    if ((threadIdx.x & 63u) == 0u) { wave_nodes[threadIdx.x >> 6] = n_nodes; wave_tris[threadIdx.x >> 6] = n_tris; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t sum = 0;
-        for (uint32_t i = 0; i < 1024u; ++i) { const uint32_t v = part[i]; part[i] = sum; sum += v; }
-        p.unit_counts_out[0] = sum;
+        const uint32_t nn = (wave_nodes[0] + wave_nodes[1]) + (wave_nodes[2] + wave_nodes[3]), nt = (wave_tris[0] + wave_tris[1]) + (wave_tris[2] + wave_tris[3]);
+        if (nn) atomicAdd(p.unit_counts_out + 2, nn);
+        if (nt) atomicAdd(p.unit_counts_out + 3, nt);
     }
-    __syncthreads();
-    uint32_t at = part[threadIdx.x];
-    for (uint32_t u = lo; u < hi; ++u) if (!p.unit_empty_out[u]) p.unit_list_out[at++] = u;
 }
 
 // Resolve (Renderer.cpp:68-79): image = tonemap(accum / frame_index), over the bands this context owns.
@@ -2491,8 +2561,7 @@ extern "C" hipError_t rt_launch_column_collect(const RtParams* p, hipStream_t s)
     hipLaunchKernelGGL(rt_column_count_kernel, dim3(blocks), dim3(256), 0, s, *p);
     hipLaunchKernelGGL(rt_column_scan_kernel, dim3(1), dim3(1024), 0, s, *p, blocks);
     hipLaunchKernelGGL(rt_column_assign_kernel, dim3(blocks), dim3(256), 0, s, *p);
-    const unsigned boxes = (p->column_cap + 15u) / 16u + (p->column_cap + 63u) / 64u + (p->column_cap + 255u) / 256u;
-    hipLaunchKernelGGL(rt_column_chunks_kernel, dim3((boxes + 255u) / 256u), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(rt_column_chunks_kernel, dim3((p->column_cap + 255u) / 256u), dim3(256), 0, s, *p);     // (a workgroup per 256 slots; those beyond the count return at once)
     return hipGetLastError();
 }
 
@@ -2548,18 +2617,23 @@ extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_in
     return hipGetLastError();
 }
 
+// Words of RtParams::unit_block_out the classification needs: one per 64 units.
+extern "C" unsigned rt_units_blocks(unsigned n_units) { return (n_units + 63u) / 64u; }
+
 extern "C" hipError_t rt_launch_units_classify(const RtParams* p, hipStream_t s)
 {
-    const unsigned per_block = 256u / RT_UNIT;
-    hipLaunchKernelGGL(rt_units_classify_kernel, dim3((p->n_units + per_block - 1u) / per_block), dim3(256), 0, s, *p);
-    hipLaunchKernelGGL(rt_units_compact_kernel, dim3(1), dim3(1024), 0, s, *p);
+    const unsigned blocks = rt_units_blocks(p->n_units);
+    hipLaunchKernelGGL(rt_units_classify_kernel, dim3(blocks), dim3(1024), 0, s, *p);
+    hipLaunchKernelGGL(rt_units_scan_kernel, dim3(1), dim3(1024), 0, s, *p, blocks);
+    hipLaunchKernelGGL(rt_units_assign_kernel, dim3((blocks + 3u) / 4u), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 
-extern "C" hipError_t rt_launch_units_entry(const RtParams* p, hipStream_t s)
+// `max_listed`: an upper bound of the listed units (their number itself is read on the device).
+extern "C" hipError_t rt_launch_units_entry(const RtParams* p, unsigned max_listed, hipStream_t s)
 {
     const unsigned per_block = 256u / RT_UNIT;
-    if (p->n_list) hipLaunchKernelGGL(rt_units_entry_kernel, dim3((p->n_list + per_block - 1u) / per_block), dim3(256), 0, s, *p);
+    if (max_listed) hipLaunchKernelGGL(rt_units_entry_kernel, dim3((max_listed + per_block - 1u) / per_block), dim3(256), 0, s, *p);
     return hipGetLastError();
 }
 

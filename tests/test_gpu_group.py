@@ -84,6 +84,38 @@ def test_group_sample_split_sums_in_context_order(rt, orc, mode):
         assert np.array_equal(bits(m.read_accum().reshape(-1, 3)), bits(acc)), "context %d" % i
 
 
+@pytest.mark.parametrize("split", ["tiles", "samples"])
+def test_group_issues_on_every_context_before_it_waits_for_any(rt, orc, split, monkeypatch):
+    """In a tree large enough for parking (here forced: RT_PARK_MIN_NODES=1) every trace launch is followed by a wait for one
+    word, the number of paths it parked.  A group issues the launch on all its contexts first and waits afterwards, so its GPUs
+    trace side by side: when the issue phase of a call returns, the first context's kernel is still running
+    (rt_group_issue_overlap; three contexts on one GPU, a frame of several hundred microseconds).  Bits as ever."""
+    from raytracer_amd import scenes
+    monkeypatch.setenv("RT_PARK_MIN_NODES", "1")
+    scene, osc = make_scene(rt, orc, mesh=scenes.displaced_grid(60, x_range=(-1.5, 1.5), z_range=(-3.0, 0.0), mat_offset=0))
+    w, h, per = 640, 360, 2
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    g = rt.GroupRenderer([0, 0, 0], split=split, frames_per_device=per)
+    L = g._L
+    assert L.rt_group_issue_overlap(g._g) == -1
+    st = g.GetSettings(); st.SceneMode, st.Bounces = 2, 6
+    g.OnResize(w, h)
+    g.Render(scene, cam)
+    overlaps = [L.rt_group_issue_overlap(g._g)]
+    g.Render(scene, cam)
+    overlaps.append(L.rt_group_issue_overlap(g._g))
+    # contexts 1 and 2 were issued while context 0's launch was still on the device (every one of the three parks: mode 2)
+    assert max(overlaps) >= 1, overlaps
+    frames = 2 if split == "tiles" else 2 * 3 * per
+    want_acc, want_img = oracle_frames(orc, osc, cam, w, h, 2, 6, frames)
+    got = g.read_accum().reshape(-1, 3)
+    if split == "tiles":
+        assert np.array_equal(bits(got), bits(want_acc))
+        assert np.array_equal(bits(g.GetImage().data.reshape(-1, 4)), bits(want_img))
+    else:
+        assert np.all(np.abs(got - want_acc) <= 1e-4 + 1e-4 * np.abs(want_acc))
+
+
 def test_group_errors(rt):
     from raytracer_amd import _capi
     with pytest.raises(_capi.RtError):

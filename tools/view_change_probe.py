@@ -17,6 +17,9 @@ def main():
     steps = 16
     if "--steps" in argv:
         i = argv.index("--steps"); steps = int(argv[i + 1]); del argv[i:i + 2]
+    kinds = ("rotate", "translate")
+    if "--only" in argv:
+        i = argv.index("--only"); kinds = (argv[i + 1],); del argv[i:i + 2]
     args = argv
     for cid in [int(a) for a in args] or [3]:
         cfg = bench.CONFIGS[cid]
@@ -28,7 +31,7 @@ def main():
         for f in range(1, 4):
             r.render_only(f)
         r.sync()
-        print(json.dumps({"config": cid, "view_change": bench.view_change(r, scene, cam, cfg, torch, steps)}), flush=True)
+        print(json.dumps({"config": cid, "view_change": bench.view_change(r, scene, cam, cfg, torch, steps, kinds)}), flush=True)
         del r, scene
 
 
