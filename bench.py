@@ -466,7 +466,7 @@ def main():
         # screen-tile split: every rank renders all K frames of its own 16-row bands; bands are gathered on rank 0 per frame
         r.set_bands(rank, world)
         warm = list(range(1, W + 1)); frames = list(range(1, K + 1))
-        bands = rtd.BandGather(rtd.image_tensor(r), rank, world) if use_dist else None
+        bands = rtd.BandGather(lambda: rtd.image_tensor(r), rank, world) if use_dist else None
         acc_t = None
     else:
         # sample split: rank r renders frame indices r+1, r+1+N, ... (world == 1: 1, 2, 3, ...)

@@ -123,7 +123,7 @@ typedef struct { uint64_t launches; double total_ms; double last_ms; double prep
 /* Renderer::Renderer() (Renderer.cpp:16-18) on HIP device `device_id`. Returns NULL on failure. */
 rt_ctx*     rt_create(int device_id);
 void        rt_destroy(rt_ctx*);
-const char* rt_last_error(const rt_ctx*);          /* ctx may be NULL: error of the last failed rt_create */
+const char* rt_last_error(const rt_ctx*);          /* ctx may be NULL: this thread's last error from a call without a context */
 /* Run the context's work on `hip_stream` (a hipStream_t) instead of its own stream; NULL restores its own. */
 int         rt_set_stream(rt_ctx*, void* hip_stream);
 
@@ -216,7 +216,12 @@ int rt_render_frames(rt_ctx*, uint32_t frame_index, uint32_t n);
    what d_accum holds.  Same kernels as rt_render, so the same bits.  Asynchronous on `hip_stream` (a hipStream_t, NULL = the
    default stream).  Fixed limits, RT_E_LIMIT beyond them: width*height <= 2,097,152 (1920x1080 fits), 32 spheres, 32 materials.
    Every call on a GPU uses that GPU's one array: calls that overlap in time on one GPU race; calls ordered by a stream or by
-   events do not, and nothing has to survive in the array from one call to the next.  Errors: rt_last_error(NULL). */
+   events do not, and nothing has to survive in the array from one call to the next.  Errors: rt_last_error(NULL), kept per
+   calling thread.  Set-up: the first use of a device looks up that device's address of the array and the size of the persistent
+   grid (hipGetSymbolAddress, a device and an occupancy query: no allocation, but not calls to make inside a stream capture).
+   rt_render_spheres_noalloc_setup(device) does exactly that and nothing else; rt_create(device) does it too.  Call one of them, or
+   make one ordinary call, on every device BEFORE the first call under graph capture there. */
+int rt_render_spheres_noalloc_setup(int device);
 int rt_render_spheres_noalloc(int device, void* hip_stream, const rt_sphere* spheres, uint32_t n_spheres,
                               const rt_material* materials, uint32_t n_materials, const rt_settings* settings,
                               const float cam_pos[3], const float inv_proj[16], const float inv_view[16],

@@ -20,7 +20,7 @@ ID_TRI_BIT = 0x40000000
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_stream", "rt_resize", "rt_set_settings", "rt_set_spheres",
     "rt_set_materials", "rt_set_mesh", "rt_set_kdtree", "rt_traversal_in_use", "rt_set_camera", "rt_set_ray_dirs", "rt_set_bands", "rt_render",
-    "rt_render_frames", "rt_render_spheres_noalloc", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_map_image", "rt_map_image_pipelined", "rt_read_accum", "rt_set_record_ids",
+    "rt_render_frames", "rt_render_spheres_noalloc", "rt_render_spheres_noalloc_setup", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_map_image", "rt_map_image_pipelined", "rt_read_accum", "rt_set_record_ids",
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters", "rt_read_wave_clock",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_set_kernel_timing", "rt_device_accum", "rt_device_image",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_last_error", "rt_group_render_tiles",
@@ -94,6 +94,7 @@ def lib():
         "rt_set_ray_dirs": ([vp, vp, sz], C.c_int), "rt_set_bands": ([vp, u32, u32], C.c_int),
         "rt_render": ([vp, u32], C.c_int), "rt_render_frames": ([vp, u32, u32], C.c_int),
         "rt_render_spheres_noalloc": ([C.c_int, vp, vp, u32, vp, u32, vp, vp, vp, vp, u32, u32, u32, vp, vp], C.c_int),
+        "rt_render_spheres_noalloc_setup": ([C.c_int], C.c_int),
         "rt_resolve": ([vp, u32], C.c_int), "rt_reset_accum": ([vp], C.c_int), "rt_sync": ([vp], C.c_int), "rt_read_image": ([vp, vp], C.c_int), "rt_map_image": ([vp], vp), "rt_map_image_pipelined": ([vp], vp),
         "rt_read_accum": ([vp, vp], C.c_int), "rt_set_record_ids": ([vp, C.c_int], C.c_int),
         "rt_read_primary_ids": ([vp, vp], C.c_int), "rt_read_ray_dirs": ([vp, vp], C.c_int),

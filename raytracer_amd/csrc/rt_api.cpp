@@ -39,7 +39,9 @@ extern "C" hipError_t rt_static_setup(int device);               // rt_static.hi
 
 namespace {
 
-std::string g_create_error;
+// the message of the entry points that have no context (rt_create, rt_group_create, rt_render_spheres_noalloc): per thread, so that
+// two threads failing at once neither race on it nor read each other's text
+thread_local std::string g_create_error;
 
 template <class T>
 struct DevBuf {

@@ -4,14 +4,16 @@
 //
 //   rt_bench [--config 1|2|3|4|5] [--width W --height H --bounces B --mode 0|1|2 --grid N --scale S]
 //            [--frames K] [--warmup W] [--frames-per-launch F] [--d2h 0|1|2] [--devices 0,1,...] [--split tiles|samples]
-//            [--reuse-first-hits 0|1]
+//            [--reuse-first-hits 0|1] [--moving 0|1]
 //
 // --config picks one of the five benchmark configurations (default 2: the default sphere scene at 1920x1080, 5 bounces);
 // the other options override it.  --d2h 1 ends every Render with the frame in host memory (rt_map_image), as
 // Renderer::Render does (Renderer.cpp:134); 2 = the pipelined hand-off; 0 (default) leaves frames in HBM.
 // --devices lists the GPUs of a group (a device may be repeated); --split tiles (one frame over all GPUs, default) or
 // samples (every GPU its own frame indices).  --reuse-first-hits 1 sets rt_settings.reuse_first_hits (mesh scenes keep each
-// pixel's primary hit while the camera stands still).  Prints one JSON line: ms per frame (wall clock around the Render calls,
+// pixel's primary hit while the camera stands still).  --moving 1: the camera turns by 2 mrad about the vertical axis before
+// every Render and the accumulation restarts, as RaytracerLayer::OnUpdate does whenever Camera::OnUpdate reports motion
+// (RaytracerApp.cpp:259-263): every Render is the first frame of a new view.  Prints one JSON line: ms per frame (wall clock around the Render calls,
 // what the reference shows as "Last render"), Mrays/s from the device's ray counter, trace-kernel ms from HIP events.
 #include <chrono>
 #include <cmath>
@@ -38,6 +40,7 @@ struct Options {
     std::vector<int> devices{0};
     bool samples = false;
     int reuse_first_hits = 0;
+    int moving = 0;
 };
 
 void preset(Options& o, int config)
@@ -130,6 +133,7 @@ int main(int argc, char** argv)
         else if (a == "--d2h") o.d2h = atoi(val());
         else if (a == "--split") o.samples = !strcmp(val(), "samples");
         else if (a == "--reuse-first-hits") o.reuse_first_hits = atoi(val()) != 0;
+        else if (a == "--moving") o.moving = atoi(val()) != 0;
         else if (a == "--devices") {
             o.devices.clear();
             for (const char* p = val(); *p;) { o.devices.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
@@ -154,9 +158,16 @@ int main(int argc, char** argv)
         build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     // ---- camera (Camera(70, 0.05, 100), RaytracerApp.cpp:24; Camera.cpp:11-19,122-132)
-    float pos[3] = {0.0f, 1.0f, 2.0f}, fwd[3], proj[16], inv_proj[16], view[16], inv_view[16];
-    rt_host_camera_default_forward(fwd);
+    float pos[3] = {0.0f, 1.0f, 2.0f}, fwd0[3], fwd[3], proj[16], inv_proj[16], view[16], inv_view[16];
+    rt_host_camera_default_forward(fwd0);
+    memcpy(fwd, fwd0, sizeof fwd);
     rt_host_camera_matrices(70.0f, 0.05f, 100.0f, o.width, o.height, pos, fwd, proj, inv_proj, view, inv_view);
+    uint32_t pose = 0;
+    auto turn = [&]() {                            // Camera::OnUpdate on mouse motion (Camera.cpp:80-100): a new forward direction, new matrices
+        const float a = 0.002f * (float)(++pose), c = std::cos(a), s = std::sin(a);
+        fwd[0] = fwd0[0] * c + fwd0[2] * s; fwd[1] = fwd0[1]; fwd[2] = -fwd0[0] * s + fwd0[2] * c;
+        rt_host_camera_matrices(70.0f, 0.05f, 100.0f, o.width, o.height, pos, fwd, proj, inv_proj, view, inv_view);
+    };
 
     rt_group* g = rt_group_create(o.devices.data(), (int)n_dev);
     if (!g) die("rt_group_create", rt_last_error(nullptr));
@@ -179,6 +190,7 @@ int main(int argc, char** argv)
 
     uint32_t frame_index = 1;                      // m_frameindex (Renderer.h:121)
     auto render = [&]() {                          // one pass of RaytracerLayer::Render; returns the Renders it made
+        if (o.moving) { turn(); frame_index = 1; }  // RaytracerApp.cpp:259-263
         upload();
         uint32_t made;
         int rc;
@@ -215,10 +227,10 @@ int main(int argc, char** argv)
     printf("{\"bench\": \"rt_bench (C++ host, headless)\", \"config\": %d, \"width\": %u, \"height\": %u, \"bounces\": %u, \"scene_mode\": %d, "
            "\"triangles\": %zu, \"kd_nodes\": %u, \"kd_depth\": %u, \"kd_build_s\": %.2f, \"devices\": %u, \"split\": \"%s\", "
            "\"frames\": %u, \"frames_per_launch\": %u, \"d2h\": %d, \"ms_per_frame\": %.4f, \"mrays_per_s\": %.1f, \"rays_per_frame\": %.0f, "
-           "\"trace_kernel_ms_per_frame_gpu0\": %.4f, \"reuse_first_hits\": %d, \"primary_hits_reused_per_frame\": %.0f, \"empty_unit_rays_per_frame\": %.0f}\n",
+           "\"trace_kernel_ms_per_frame_gpu0\": %.4f, \"reuse_first_hits\": %d, \"primary_hits_reused_per_frame\": %.0f, \"empty_unit_rays_per_frame\": %.0f, \"moving\": %d}\n",
            o.config, o.width, o.height, o.bounces, o.mode, mesh.tris.size() / 3, flat.n_nodes, depth, build_s, n_dev,
            n_dev == 1 ? "none" : (o.samples ? "samples" : "tiles"), made, o.per_launch, o.d2h, dt / made * 1e3, (double)rays / dt / 1e6,
-           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0, o.reuse_first_hits, (double)reused / made, (double)skipped / made);
+           (double)rays / made, kframes ? kernel_ms / (double)kframes : 0.0, o.reuse_first_hits, (double)reused / made, (double)skipped / made, o.moving);
     rt_group_destroy(g);
     if (kd) rt_host_kd_free(kd);
     return 0;

@@ -105,6 +105,13 @@ extern "C" hipError_t rt_static_setup(int device)
     return d.status;
 }
 
+extern "C" int rt_render_spheres_noalloc_setup(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return fail(RT_E_ARG, "rt_render_spheres_noalloc_setup: device %d", device);
+    if (hipError_t e = rt_static_setup(device)) return fail(RT_E_HIP, "rt_render_spheres_noalloc_setup: device %d: %s", device, hipGetErrorString(e));
+    return RT_OK;
+}
+
 extern "C" int rt_render_spheres_noalloc(int device, void* hip_stream, const rt_sphere* spheres, uint32_t n_spheres,
                                          const rt_material* materials, uint32_t n_materials, const rt_settings* settings,
                                          const float cam_pos[3], const float inv_proj[16], const float inv_view[16],

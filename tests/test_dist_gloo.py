@@ -64,6 +64,28 @@ def _worker(rank, world, port, tmp):
     else:
         assert out is None
     dist.barrier()
+
+    # a sub-group that leaves global rank 0 out: dst is a GLOBAL rank there too (ranks 1 and 2 are places 0 and 1 of the group)
+    if world == 3:
+        sub = dist.new_group([1, 2])
+        if rank >= 1:
+            part = torch.full((4, 5, 4), float(rank))
+            rtd.sum_accumulation(part, dst=1, group=sub)
+            want = 3.0 if rank == 1 else float(rank)                # only dst holds the total
+            assert torch.all(part[..., :3] == want) and torch.all(part[..., 3] == float(rank))
+            place = rank - 1
+            rows2 = rtd.band_rows(H, place, 2)
+            mine2 = np.zeros((H, W, 4), np.float32)
+            mine2[rows2] = full_img.reshape(H, W, 4)[rows2]
+            holder = {"t": torch.from_numpy(mine2)}
+            bg = rtd.BandGather(lambda: holder["t"], place, 2, dst=1, group=sub)
+            holder["t"] = holder["t"].clone()                       # the frame buffer moved: the gather must follow it
+            out2 = bg.gather()
+            if rank == 1:
+                assert out2 is holder["t"] and np.array_equal(out2.numpy(), full_img.reshape(H, W, 4))
+            else:
+                assert out2 is None
+        dist.barrier()
     dist.destroy_process_group()
 
 

@@ -132,7 +132,7 @@ def test_rt_bench_headless_cpp_host():
     assert os.path.exists(exe), "rt_bench is built by raytracer_amd/csrc/Makefile"
     base = [exe, "--config", "3", "--width", "320", "--height", "200", "--grid", "150", "--frames", "8", "--warmup", "1"]
     runs = {"single": [], "x4": ["--frames-per-launch", "4"], "reuse": ["--frames-per-launch", "4", "--reuse-first-hits", "1"],
-            "d2h": ["--d2h", "2"], "tiles": ["--devices", "0,0", "--split", "tiles", "--frames-per-launch", "2"]}
+            "d2h": ["--d2h", "2"], "moving": ["--moving", "1"], "tiles": ["--devices", "0,0", "--split", "tiles", "--frames-per-launch", "2"]}
     out = {}
     for name, extra in runs.items():
         p = subprocess.run(base + extra, capture_output=True, text=True, timeout=120)
@@ -140,7 +140,8 @@ def test_rt_bench_headless_cpp_host():
         out[name] = json.loads(p.stdout.strip().splitlines()[-1])
         assert out[name]["frames"] == 8 and out[name]["ms_per_frame"] > 0 and out[name]["mrays_per_s"] > 0
         assert out[name]["trace_kernel_ms_per_frame_gpu0"] > 0, name          # (some launch of every run is a timed one)
-    rays = {name: o["rays_per_frame"] for name, o in out.items()}
+    assert out["moving"]["moving"] == 1 and out["moving"]["rays_per_frame"] >= 320 * 200
+    rays = {name: o["rays_per_frame"] for name, o in out.items() if name != "moving"}           # (a turning camera sees other rays)
     assert len(set(rays.values())) == 1 and rays["single"] >= 320 * 200, rays
     assert out["reuse"]["primary_hits_reused_per_frame"] > 0 and out["single"]["primary_hits_reused_per_frame"] == 0
     assert out["reuse"]["primary_hits_reused_per_frame"] + out["reuse"]["empty_unit_rays_per_frame"] == 320 * 200

@@ -822,6 +822,42 @@ def test_config2_1080p_sphere_scene_ids_and_accumulation(rt, orc, renderer):
     assert np.array_equal(bits(sums[0][rows]), bits(acc.reshape(h, w, 3)[rows]))
 
 
+def test_config1_720p_sphere_scene_hundred_accumulated_frames(rt, orc, renderer):
+    """BASELINE configs[0] at its own size and depth: the default sphere scene at 1280x720, 5 bounces, 100 accumulated frames (the
+    reference's CPU-runnable case).  The oracle renders every 8th row of every frame (rows are independent: a pixel's random
+    stream is its own); on those rows the sums after 100 frames, the 100th frame's image and the ids are the library's bits."""
+    scene, osc = make_scene(rt, orc)
+    w, h, frames, step = 1280, 720, 100, 8
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    st = renderer.GetSettings()
+    st.SceneMode, st.Bounces, st.UseACE_Color, st.AntiAliasing, st.Accumulate, st.Seed = 1, 5, True, False, True, 1337
+    renderer.OnResize(w, h); renderer.ResetFrameIndex(); renderer.record_ids(True); renderer.reset_counters()
+    renderer.download = False
+    try:
+        for _ in range(frames):
+            renderer.Render(scene, cam)                        # one launch per Render, as the application makes them
+    finally:
+        renderer.download = True
+    assert renderer.GetFrameIndex() == frames + 1
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.full(h * w, -7, np.int32)
+    cnt = orc.Counters()
+    ost = orc.Settings(1, 1, 1, 0, 5)
+    for f in range(1, frames + 1):
+        osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, primary_ids=ids if f == 1 else None, counters=cnt,
+                         nthreads=16, row_step=step)
+    rows = np.arange(0, h, step)
+    got_acc = renderer.read_accum().reshape(h, w, 3)[rows]; got_img = renderer.read_image().reshape(h, w, 4)[rows]
+    got_ids = renderer.read_primary_ids().reshape(h, w)[rows]
+    assert np.array_equal(got_ids, ids.reshape(h, w)[rows])
+    assert np.array_equal(bits(got_acc), bits(acc.reshape(h, w, 3)[rows])), "sums after %d frames" % frames
+    assert np.all(np.abs(got_acc - acc.reshape(h, w, 3)[rows]) <= 1e-5 + 1e-5 * np.abs(acc.reshape(h, w, 3)[rows]))     # the stated tolerance
+    assert np.array_equal(bits(got_img), bits(img.reshape(h, w, 4)[rows])), "image of frame %d" % frames
+    # the rays of the rows the oracle rendered, scaled: the library traced every row (3.668 rays per pixel-sample in this scene)
+    rays = renderer.read_counters().rays
+    assert abs(rays / (w * h * frames) - cnt.rays / (w * len(rows) * frames)) < 0.02
+
+
 def test_config3_70k_mesh_1080p_primary_ids(rt, orc, renderer):
     """BASELINE configs[2] at full size: primary ids of all 1080p pixels through the 69,938-triangle tree, bit-exact;
     then one 8-bounce frame at a sixteenth of the rows against the oracle."""

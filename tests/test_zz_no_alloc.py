@@ -76,3 +76,71 @@ def test_noalloc_entry_point_matches_rt_render_twice_in_a_row():
     many = np.concatenate([sph] * 4)
     rc = L.rt_render_spheres_noalloc(0, handle, _capi.ptr(many), len(many), *args[2:], 64, 64, 1, C.c_void_p(buf.data_ptr()), C.c_void_p(buf.data_ptr()))
     assert rc == -5
+
+
+def test_noalloc_allocates_nothing_replays_from_a_graph_and_equals_the_oracle(orc):
+    """What the entry point exists for: after its set-up on the device, calls change neither the device's free memory nor need
+    anything a stream capture forbids -- three Renders captured into a HIP graph (torch's capture runs in the mode that fails any
+    allocation made meanwhile) replay to the same bits.  Those bits are the oracle's.  A scene without spheres is a frame of misses."""
+    import torch
+    import raytracer_amd as rt
+    from raytracer_amd import _capi, scenes
+    from raytracer_amd.scenes import MATERIAL_DTYPE, SPHERE_DTYPE
+    L = _capi.lib()
+    assert L.rt_render_spheres_noalloc_setup(0) == 0, L.rt_last_error(None)
+    w, h, frames, bounces = 160, 96, 3, 5
+    cam = rt.Camera(70.0, 0.05, 100.0); cam.OnResize(w, h)
+    sph = np.ascontiguousarray(scenes.default_spheres(), SPHERE_DTYPE); mats = np.ascontiguousarray(scenes.default_materials(), MATERIAL_DTYPE)
+    st = _capi.RtSettings(1, 1, 1, 0, bounces, 1337, 0, 0)
+    acc = torch.full((h, w, 4), 7.0, dtype=torch.float32, device="cuda:0")
+    img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda:0")
+
+    def calls(stream_handle, spheres=sph):
+        for f in range(1, frames + 1):
+            rc = L.rt_render_spheres_noalloc(0, stream_handle, _capi.ptr(spheres) if len(spheres) else None, len(spheres), _capi.ptr(mats), len(mats),
+                                             C.byref(st), _capi.ptr(cam.GetPosition()), _capi.ptr(cam.GetInverseProjection()),
+                                             _capi.ptr(cam.GetInverseView()), w, h, f, C.c_void_p(acc.data_ptr()), C.c_void_p(img.data_ptr()))
+            assert rc == 0, L.rt_last_error(None)
+
+    # the oracle's three frames
+    osc = orc.Scene(); osc.set_spheres(sph); osc.set_materials(mats)
+    dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
+    want_acc = np.zeros((h * w, 3), np.float32); want_img = np.zeros((h * w, 4), np.float32)
+    for f in range(1, frames + 1):
+        osc.render_frame(orc.Settings(1, 1, 1, 0, bounces), cam.GetPosition(), dirs, w, h, f, want_acc, want_img)
+
+    def check(what):
+        torch.cuda.synchronize()
+        assert np.array_equal(bits(acc.cpu().numpy().reshape(-1, 4)[:, :3]), bits(want_acc)), what
+        assert np.array_equal(bits(img.cpu().numpy().reshape(-1, 4)), bits(want_img)), what
+
+    stream = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(stream):
+        calls(C.c_void_p(stream.cuda_stream))              # (an ordinary call first: whatever the runtime sets up lazily is set up)
+        check("first calls")
+        free_before = torch.cuda.mem_get_info(0)[0]
+        calls(C.c_void_p(stream.cuda_stream))
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(0)[0] == free_before, "the calls changed the device's free memory"
+        check("calls after the set-up")
+    # captured: nothing but kernel launches may happen in there
+    graph = torch.cuda.CUDAGraph()
+    acc.fill_(3.0); img.zero_()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        calls(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for replay in range(2):
+        acc.fill_(5.0); img.zero_()
+        graph.replay()
+        check("graph replay %d" % replay)
+    # no spheres at all: every ray misses
+    none = np.zeros(0, SPHERE_DTYPE)
+    with torch.cuda.stream(stream):
+        calls(C.c_void_p(stream.cuda_stream), none)
+    torch.cuda.synchronize()
+    osc.set_spheres(none)
+    want_acc[:] = 0; want_img[:] = 0
+    for f in range(1, frames + 1):
+        osc.render_frame(orc.Settings(1, 1, 1, 0, bounces), cam.GetPosition(), dirs, w, h, f, want_acc, want_img)
+    check("a scene without spheres")
+    assert not want_acc.any()
