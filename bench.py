@@ -49,6 +49,10 @@ CONFIGS = {
     # the reference's |determinant| < 1e-5 rejection, Intersections.cpp:64, and the mesh could not be hit at all.)
     4: dict(name="9,999,392-triangle displaced grid (30x30 units) + KD tree in HBM, 3840x2160, 8 bounces, screen-tile split (BASELINE configs[3])",
             w=3840, h=2160, bounces=8, mode=0, mesh=("grid", 2236, 10.0), split="tile"),
+    # The reference application's own kind of scene (RaytracerApp.cpp:27-131 loads a Cornell-box OBJ): 32 wall-sized triangles and a
+    # 5,000-triangle water surface in the transparent material "water", through the OBJ ingest.  Not a BASELINE configuration.
+    6: dict(name="Cornell-box-class OBJ (32 large triangles + 5,000-triangle water surface, material \"water\"), 1920x1080, 8 bounces",
+            w=1920, h=1080, bounces=8, mode=0, mesh=("cornell", 50)),
     5: dict(name="default spheres + 9,999,392-triangle mesh, 3840x2160, 8 bounces, progressive, sample split (BASELINE configs[4])",
             w=3840, h=2160, bounces=8, mode=2, mesh=("grid", 2236, 10.0)),
 }
@@ -97,6 +101,16 @@ def build_scene(cfg):
     scene = rt.Scene()
     scene.spheres = scenes.default_spheres()
     mats = scenes.default_materials()
+    if cfg["mesh"] and cfg["mesh"][0] == "cornell":
+        # as the application does it: the file's materials first, its own seven after them (RaytracerApp.cpp:132-187)
+        import tempfile
+        from raytracer_amd import ingest
+        with tempfile.TemporaryDirectory() as tmp:
+            verts, tris, normals9, tri_mat, mats, names = ingest.load_obj(scenes.write_cornell_class_obj(tmp, cfg["mesh"][1]), app_materials=True)
+        scene.spheres = scenes.default_spheres(mat_offset=len(names))
+        scene.set_triangles(verts, tris, normals9, tri_mat, max_nodes=4_000_000, nthreads=min(16, host_threads()))
+        scene.materials = mats
+        return scene
     if cfg["mesh"]:
         kind, n = cfg["mesh"][:2]
         if kind == "grid":
@@ -159,10 +173,59 @@ def _traffic_from_profile(config, frames_per_launch=1):
         return None
 
 
+def _issue_from_profile(config, frames_per_launch=1):
+    """Wave-instructions per launch of the trace kernel from the committed PMC pass (profiles/issue.json), or None."""
+    p = os.path.join(ROOT, "profiles", "issue.json")
+    key = "config%d" % config + ("_x%d" % frames_per_launch if frames_per_launch > 1 else "")
+    try:
+        with open(p) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+SIMDS = 1024                         # 256 CUs x 4
+ISSUE_CYCLES = 2.0                   # a SIMD starts a wave-instruction every other cycle at best (32 lanes per cycle, 64-lane waves)
+
+
+def issue_roofline(config, frames_per_launch, kernel_s, clock_hz):
+    """The bound these kernels run against: the rate at which the chip's SIMDs can start wave-instructions of ANY kind (vector,
+    scalar, memory, LDS: a wave issues in order).  Instructions per launch from the committed PMC pass, time from this run."""
+    rec = _issue_from_profile(config, frames_per_launch)
+    if not rec or not rec.get("instructions") or not kernel_s:
+        return None
+    peak = SIMDS * clock_hz / ISSUE_CYCLES
+    achieved = rec["instructions"] / kernel_s
+    return {"bound": "instruction issue", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "T wave-instructions/s", "frac": achieved / peak,
+            "instructions_per_launch": rec["instructions"], "valu": rec.get("valu"), "salu": rec.get("salu"), "vmem": rec.get("vmem"),
+            "lds": rec.get("lds"), "smem": rec.get("smem"), "valu_lane_use": rec.get("valu_lane_use"),
+            "wave_cycles_waiting": rec.get("wave_cycles_waiting"), "clock_hz": clock_hz,
+            "peak_note": "%d SIMDs x clock / %.0f cycles per wave-instruction" % (SIMDS, ISSUE_CYCLES),
+            "source": rec.get("source", "") + "; committed, not measured in this run"}
+
+
+def chip_busy(r, frame=1):
+    """Share of the chip's wave slots that held a running wave between the first wave's start and the last wave's end of one
+    Render (per-wave clocks of the timed kernel, one untimed launch): what is left of 1 is waves that ended early."""
+    r.set_stats(2)
+    try:
+        r.render_only(frame)
+        wc = r.read_wave_clock()
+    finally:
+        r.set_stats(False)
+    if not len(wc):
+        return None
+    start, end = wc[:, 0].astype(np.float64), wc[:, 1].astype(np.float64)
+    span = end.max() - start.min()
+    return {"fraction": float((end - start).sum() / (len(wc) * span)) if span > 0 else None, "waves": int(len(wc)),
+            "span_us": float(span / 100.0), "waiting_without_a_path": float(wc[:, 6].astype(np.float64).sum() / max((end - start).sum(), 1.0)),
+            "note": "sum over waves of (end - start) / (waves x (last end - first start)), 100 MHz clock, one Render"}
+
+
 TRAFFIC_SOURCE = "profiles/traffic.json: FETCH_SIZE + WRITE_SIZE of a rocprofv3 --pmc pass over this command, committed; not measured in this run"
 
 
-def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, profiling=False):
+def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, profiling=False, clock_hz=2.4e9):
     """Price the trace kernel of the timed launches (cnt / kt: their counters and event times) against its bound."""
     px = cfg["w"] * cfg["h"]
     timed = max(kt.launches, 1)                                      # launches with HIP events around them (KERNEL_TIMING_EVERY)
@@ -182,6 +245,8 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
                 "kernel": "rt_trace_spheres_kernel", "kernel_avg_ms": avg_kernel_s * 1e3, "launches": launches,
                 "launches_timed": int(kt.launches), "kernel_time_source": KERNEL_TIME_SOURCE,
                 "flops_per_ray": FLOPS_PER_SPHERE_RAY(len(scene.spheres)), "rays_per_launch": rays_per_launch,
+                "issue": issue_roofline(config_id, frames_per_launch, avg_kernel_s, clock_hz),
+                "chip_busy": chip_busy(r) if not profiling else None,
                 "note": "fp32 VALU without FMA (bit-exact contract); no MFMA in this path; accum and dirs are float4 "
                         "(32 B + 16 B per pixel against the 24 B + 0 B of the 40 B/pixel model), hence traffic about twice the algorithmic bytes"}
     # node / triangle counts of the same frames, from an untimed pass with the counting kernel
@@ -242,15 +307,18 @@ def roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, world, p
             "primary_walk_steps_spared_per_launch": {"nodes": spared_nodes, "tris": spared_tris}, "traversal": order_used, "reference_order_counts": ref_counts,
             "grazing_ties": order_ties,
             "near_tie_rewalks_per_frame": per_frame(cnt.near_ties),
+            "issue": issue_roofline(config_id, frames_per_launch, avg_kernel_s, clock_hz),
+            "chip_busy": chip_busy(r) if not profiling else None,
             "note": "algorithmic bytes = 32 B x nodes visited + 40 B x triangles tested by the trace kernel (+40 B per traced ray for the hit's "
                     "normals/material, +40 B per pixel for accumulation and image), counts from the device counters of the walk order "
                     "that was timed; primary rays of 16-pixel units that miss the root box altogether are not traced and not priced, nor are the first steps of primary walks that start at their unit's common entry node; `frac` prices them against the HBM peak as the contract asks, `frac_hbm_moved` is what the PMC "
-                    "counters saw reach HBM; the walk is a chain of dependent 32-48 B reads, so latency rather than bandwidth bounds it; "
-                    + ("nodes (8 x 3.6 MB) + leaf records (17 MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
+                    "counters saw reach HBM; neither is the bound that applies: the walk is a chain of dependent 32-48 B reads made by waves that issue in order, "
+                    "so `issue` (wave-instructions started per second against what the SIMDs can start) and `chip_busy` (waves that ended early) say how far the kernel is from its roof; "
+                    + ("nodes + leaf records (a few MB to a few tens of MB) sit in L2 / Infinity Cache at this size, not in HBM" if small
                        else "nodes (8 x 0.5 GB) + leaf records (2.4 GB) are HBM-resident: random 32-48 B reads")}
 
 
-def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=None, n_spheres=9):
+def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=None, n_spheres=9, config_id=0, clock_hz=2.4e9):
     """The same workload as launches of FRAMES_PER_LAUNCH Renders (rt_render_frames): what a progressive accumulation uses."""
     r.set_kernel_timing(1)
     r.reset_accum(); r.render_only(1001, FRAMES_PER_LAUNCH)                     # warm: slot planes are allocated here
@@ -271,9 +339,15 @@ def throughput_mode(r, cfg, torch, launches, rays_per_frame, bytes_per_frame=Non
         flops = rays_per_frame * FLOPS_PER_SPHERE_RAY(n_spheres) + cfg["w"] * cfg["h"] * FLOPS_PER_PIXEL_RESOLVE
         out["roofline_frac"] = flops / (kernel_ms_per_frame / 1e3) / 1e12 / PEAK_VALU_NOFMA_TFLOPS
     elif bytes_per_frame:
-        out["roofline_frac"] = bytes_per_frame / (kernel_ms_per_frame / 1e3) / 1e9 / PEAK_HBM_GBS
-        out["roofline_note"] = ("algorithmic bytes of the walk against the HBM peak; the tree data is served mostly by L1 / L2 / Infinity Cache "
-                                "in launches of 16 Renders, so this can pass 1 (profiles/traffic.json has the bytes that reach HBM per launch)")
+        # (the algorithmic bytes of the walk are served mostly by L1 / L2 / Infinity Cache in launches of 16 Renders: priced against
+        # the HBM peak they are no fraction of a bound -- what reaches HBM is)
+        launch_s = kernel_ms_per_frame / 1e3 * FRAMES_PER_LAUNCH
+        traffic = _traffic_from_profile(config_id, FRAMES_PER_LAUNCH)
+        out["algorithmic_GBs"] = bytes_per_frame / (kernel_ms_per_frame / 1e3) / 1e9
+        out["frac_hbm_moved"] = (traffic / launch_s / 1e9 / PEAK_HBM_GBS) if traffic else None
+        out["traffic_per_launch"] = traffic
+        out["traffic_source"] = TRAFFIC_SOURCE
+    out["issue"] = issue_roofline(config_id, FRAMES_PER_LAUNCH, kernel_ms_per_frame / 1e3 * FRAMES_PER_LAUNCH, clock_hz)
     return out
 
 
@@ -363,6 +437,14 @@ def view_change(r, scene, cam, cfg, torch, steps, kinds=("rotate", "translate"))
     return out
 
 
+def device_clock_hz(torch, device=0):
+    """The engine clock the device reports (its maximum: the kernels here run at or near it; rocm-smi on the box shows the same)."""
+    try:
+        return float(torch.cuda.get_device_properties(device).clock_rate) * 1e3
+    except Exception:
+        return 2.4e9
+
+
 def run_single(config_id, steps, warmup, order_name, torch, device=0):
     """One-GPU measurement of a configuration, one Render per launch, plus throughput mode.  Returns (record, scene, cam)."""
     import raytracer_amd as rt
@@ -389,12 +471,13 @@ def run_single(config_id, steps, warmup, order_name, torch, device=0):
     r.sync(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     cnt, kt = r.read_counters(), r.kernel_time()
-    roof = roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, 1)
+    clock_hz = device_clock_hz(torch, device)
+    roof = roofline(config_id, cfg, scene, r, st, order_name, frames, cnt, kt, 1, clock_hz=clock_hz)
     rec = {"config": config_id, "workload": cfg["name"], "value": cnt.rays / dt / 1e6, "unit": "Mrays/s", "steps": steps,
            "ms_per_step": dt / steps * 1e3, "rays_per_frame": cnt.rays / steps,
            "empty_unit_rays_per_frame": cnt.empty_unit_rays / steps, "roofline": roof,
            "throughput_mode": throughput_mode(r, cfg, torch, max(1, steps // FRAMES_PER_LAUNCH), cnt.rays / steps,
-                                              roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))}
+                                              roof.get("algorithmic_bytes_per_launch"), len(scene.spheres), config_id, clock_hz)}
     if cfg["mode"] != 1:
         rec["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, steps, max(1, steps // FRAMES_PER_LAUNCH))
     rec["view_change"] = view_change(r, scene, cam, cfg, torch, min(steps, 32))
@@ -510,7 +593,8 @@ def main():
     kt = r.kernel_time()
 
     if rank == 0:
-        roof = roofline(args.config, cfg, scene, r, st, args.order, frames, cnt, kt, world, bool(args.profile))
+        clock_hz = device_clock_hz(torch, local_rank)
+        roof = roofline(args.config, cfg, scene, r, st, args.order, frames, cnt, kt, world, bool(args.profile), clock_hz)
         out = {
             "metric": "Mrays/s (primary+bounce)", "value": rays_total / dt_max / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": dt_max / K * 1e3, "higher_is_better": True,
@@ -525,10 +609,14 @@ def main():
             out["profile"] = args.profile + (": %d Renders per launch in the timed region" % per_launch)
         if world == 1 and not use_dist and not args.profile:
             out["throughput_mode"] = throughput_mode(r, cfg, torch, max(1, K // FRAMES_PER_LAUNCH), rays_total / K,
-                                                     roof.get("algorithmic_bytes_per_launch"), len(scene.spheres))
+                                                     roof.get("algorithmic_bytes_per_launch"), len(scene.spheres), args.config, clock_hz)
             if cfg["mode"] != 1:
                 out["first_hit_reuse"] = first_hit_reuse(r, st, cfg, torch, K, max(1, K // FRAMES_PER_LAUNCH))
             out["with_d2h"] = with_d2h(r, torch, min(K, 32))
+            # what a caller of the drop-in Renderer::Render sees per call (the frame ends in host memory, Renderer.cpp:134), beside
+            # ms_per_step (frames resident in HBM, what `value` is quoted on)
+            out["ms_per_step_with_d2h"] = out["with_d2h"]["ms_per_step_map_image"]
+            out["ms_per_step_with_d2h_pipelined"] = out["with_d2h"]["ms_per_step_map_image_pipelined"]
             r.set_stream(stream.cuda_stream)
             out["view_change"] = view_change(r, scene, cam, cfg, torch, min(K, 32))
         if not args.no_cpu_baseline and world == 1:             # the CPU oracle is timed beside the one-GPU run only

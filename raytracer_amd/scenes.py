@@ -114,3 +114,76 @@ def cube_sphere(n=76, center=(0.0, 0.9, -1.0), radius=0.8, mat_offset=0):
     mats = np.array([make_material((0.7, 0.75, 0.8), roughness=0.6),
                      make_material((1.0, 1.0, 1.0), emission=(4.0, 4.0, 4.0), roughness=1.0)], dtype=MATERIAL_DTYPE)
     return verts, tri, normals9, tri_mat, mats
+
+
+def write_cornell_class_obj(directory, water_quads=50):
+    """A Cornell-box-class scene as OBJ + MTL text, the kind of file the reference application loads (RaytracerApp.cpp:27-131; the
+    file itself is not part of the reference tree): an open box of five quad walls, a quad light under the ceiling, a short and a
+    tall block (34 large triangles in all) and a rippled surface of water_quads x water_quads quads (5,000 triangles at 50) in the
+    material named "water", which the application makes transparent (RaytracerApp.cpp:48-49).  The box spans x in [-1, 1],
+    y in [0, 2], z in [-2, 0.4], in front of the application's default camera.  Returns the path of the .obj file."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    mtl = ["newmtl white", "Kd 0.73 0.73 0.73", "newmtl red", "Kd 0.65 0.05 0.05", "newmtl green", "Kd 0.12 0.45 0.15",
+           "newmtl light", "Kd 0.78 0.78 0.78", "Ke 8.5 6.0 2.0", "newmtl water", "Kd 0.85 0.95 1.0", "Ni 1.33", "Ns 1024"]
+    with open(os.path.join(directory, "cornell_class.mtl"), "w") as fh:
+        fh.write("\n".join(mtl) + "\n")
+    lines, nv = ["mtllib cornell_class.mtl"], [0]
+
+    def quad(mat, a, b, c, d, n):
+        lines.append("usemtl %s" % mat)
+        for q in (a, b, c, d):
+            lines.append("v %.6f %.6f %.6f" % q)
+        lines.append("vn %.6f %.6f %.6f" % n)
+        k = nv[0]
+        lines.append("f %d//%d %d//%d %d//%d %d//%d" % (k + 1, -1, k + 2, -1, k + 3, -1, k + 4, -1))
+        nv[0] += 4
+
+    x0, x1, y0, y1, z0, z1 = -1.0, 1.0, 0.0, 2.0, -2.0, 0.4
+    quad("white", (x0, y0, z1), (x1, y0, z1), (x1, y0, z0), (x0, y0, z0), (0, 1, 0))            # floor
+    quad("white", (x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1), (0, -1, 0))           # ceiling
+    quad("white", (x0, y0, z0), (x1, y0, z0), (x1, y1, z0), (x0, y1, z0), (0, 0, 1))            # back
+    quad("red", (x0, y0, z1), (x0, y0, z0), (x0, y1, z0), (x0, y1, z1), (1, 0, 0))              # left
+    quad("green", (x1, y0, z0), (x1, y0, z1), (x1, y1, z1), (x1, y1, z0), (-1, 0, 0))           # right
+    quad("light", (-0.3, 1.98, -1.1), (0.3, 1.98, -1.1), (0.3, 1.98, -0.5), (-0.3, 1.98, -0.5), (0, -1, 0))
+
+    def block(cx, cz, half, height, turn):
+        import math
+        c, s_ = math.cos(turn), math.sin(turn)
+        corner = lambda dx, dz, y: (cx + c * dx * half - s_ * dz * half, y, cz + s_ * dx * half + c * dz * half)
+        ring = [(-1, -1), (1, -1), (1, 1), (-1, 1)]
+        for i in range(4):
+            (ax, az), (bx, bz) = ring[i], ring[(i + 1) % 4]
+            nx, nz = (ax + bx) / 2.0, (az + bz) / 2.0
+            quad("white", corner(ax, az, 0.55), corner(bx, bz, 0.55), corner(bx, bz, 0.55 + height), corner(ax, az, 0.55 + height),
+                 (c * nx - s_ * nz, 0.0, s_ * nx + c * nz))
+        quad("white", corner(-1, -1, 0.55 + height), corner(1, -1, 0.55 + height), corner(1, 1, 0.55 + height), corner(-1, 1, 0.55 + height), (0, 1, 0))
+
+    # (the blocks stand in the water: their sides start above the floor, so no more than a few triangle boxes meet anywhere)
+    block(0.35, -0.6, 0.3, 0.25, -0.3)
+    block(-0.35, -1.3, 0.3, 0.9, 0.3)
+    # the water: a rippled height field just above the floor, wall to wall
+    n = int(water_quads)
+    xs = np.linspace(x0 + 0.01, x1 - 0.01, n + 1); zs = np.linspace(z0 + 0.01, z1 - 0.01, n + 1)
+    lines.append("usemtl water")
+    first = nv[0]
+    for k in range(n + 1):
+        for i in range(n + 1):
+            x, z = xs[i], zs[k]
+            y = 0.4 + 0.03 * np.sin(9.0 * x) * np.cos(7.0 * z)
+            dx, dz = 0.27 * np.cos(9.0 * x) * np.cos(7.0 * z), -0.21 * np.sin(9.0 * x) * np.sin(7.0 * z)
+            ln = np.sqrt(dx * dx + 1.0 + dz * dz)
+            lines.append("v %.6f %.6f %.6f" % (x, y, z))
+            lines.append("vn %.6f %.6f %.6f" % (-dx / ln, 1.0 / ln, -dz / ln))
+    nn_first = 6 + 10                                                          # normals written so far: one per quad above
+    for k in range(n):
+        for i in range(n):
+            a = first + k * (n + 1) + i + 1
+            b, c_, d = a + 1, a + (n + 1) + 1, a + (n + 1)
+            na, nb, nc, nd = (nn_first + (v - first) for v in (a, b, c_, d))
+            lines.append("f %d//%d %d//%d %d//%d" % (a, na, d, nd, b, nb))
+            lines.append("f %d//%d %d//%d %d//%d" % (b, nb, d, nd, c_, nc))
+    path = os.path.join(directory, "cornell_class.obj")
+    with open(path, "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    return path

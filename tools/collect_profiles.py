@@ -9,6 +9,10 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 traffic_path = os.path.join(root, "profiles", "traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+# profiles/issue.json: wave-instructions per launch of the timed trace kernel, by kind (what bench.py prices against the rate at which
+# the SIMDs can issue), from the same passes
+issue_path = os.path.join(root, "profiles", "issue.json")
+issue = json.load(open(issue_path)) if os.path.exists(issue_path) else {}
 for cfg in (1, 2, 3, 4, 5):
     for kind in ("single", "throughput"):
         d = os.path.join(root, "gpurun_out", "prof_cfg%d_%s" % (cfg, kind))
@@ -32,6 +36,23 @@ for cfg in (1, 2, 3, 4, 5):
         for k, cs in s["counters"].items():
             # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
             timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
+            if timed and "SQ_INSTS_VALU" in cs and "SQ_INSTS_SALU" in cs:
+                key = "config%d" % cfg if kind == "single" else "config%d_x16" % cfg
+                calls = cs["SQ_INSTS_VALU"]["launches"]
+                scale = calls / n_main if n_main and calls > n_main else 1.0
+                get = lambda name: cs[name]["mean"] * scale if name in cs else None
+                vmem = (get("SQ_INSTS_VMEM_RD") or 0.0) + (get("SQ_INSTS_VMEM_WR") or 0.0)
+                rec = {"kernel": k, "valu": get("SQ_INSTS_VALU"), "salu": get("SQ_INSTS_SALU"), "smem": get("SQ_INSTS_SMEM"), "vmem": vmem,
+                       "lds": get("SQ_INSTS_LDS"), "waves": get("SQ_WAVES"),
+                       "launch": "one Render" if kind == "single" else "16 Renders",
+                       "source": "rocprofv3 --pmc SQ_INSTS_* (tools/profile.sh %d %s), wave-instructions per launch, round tag %s" % (cfg, kind, tag)}
+                if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_ACTIVE_INST_VALU" in cs and cs["SQ_ACTIVE_INST_VALU"]["mean"]:
+                    # thread-cycles over 64 x instruction-cycles: the share of the lanes a VALU instruction had switched on
+                    rec["valu_lane_use"] = cs["SQ_THREAD_CYCLES_VALU"]["mean"] / (64.0 * cs["SQ_ACTIVE_INST_VALU"]["mean"])
+                if "SQ_WAIT_ANY" in cs and "SQ_WAVE_CYCLES" in cs and cs["SQ_WAVE_CYCLES"]["mean"]:
+                    rec["wave_cycles_waiting"] = cs["SQ_WAIT_ANY"]["mean"] / cs["SQ_WAVE_CYCLES"]["mean"]
+                rec["instructions"] = sum(v for v in (rec["valu"], rec["salu"], rec["smem"], rec["vmem"], rec["lds"]) if v)
+                issue[key] = rec
             if timed and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
                 key = "config%d" % cfg if kind == "single" else "config%d_x16" % cfg
                 calls = cs["FETCH_SIZE"]["launches"]
@@ -43,4 +64,5 @@ for cfg in (1, 2, 3, 4, 5):
                     "launch": "one Render" if kind == "single" else "16 Renders",
                     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile.sh %d %s, round tag %s" % (cfg, kind, tag)}
 json.dump(traffic, open(traffic_path, "w"), indent=1)
+json.dump(issue, open(issue_path, "w"), indent=1)
 print(json.dumps(traffic, indent=1))
