@@ -278,6 +278,17 @@ int rt_set_kernel_timing(rt_ctx*, uint32_t every);
 void* rt_device_accum(rt_ctx*);
 void* rt_device_image(rt_ctx*);
 
+/* ---- experiments (no counterpart in the reference; used by tools/sorted_rays_probe.py) ------------------ */
+/* One Render of a tree scene with the counting kernels that also writes down every ray that starts a walk, in the order the
+   waves start them: 8 floats per ray { origin.xyz, bits(bounce, 1 = primary) } { direction.xyz, bits(pixel) }.  *n_out = rays
+   there were (the first `cap` of them are returned).  Synchronises. */
+int rt_debug_dump_rays(rt_ctx*, uint32_t frame_index, float* out_rays8, uint32_t cap, uint32_t* n_out);
+/* The front-to-back walk of the timed kernels over a list of rays (same layout; the two words of bits are ignored), one lane
+   per ray in list order (refill 0) or a persistent grid whose lanes draw the next rays as their walks end (refill 1).
+   out_hits4 (may be NULL): { t, u, v, bits(triangle, -1 = none) } per ray; *out_ms: mean kernel time of `repeats` launches (HIP
+   events, after one launch that is not counted).  variant 0 / 1 only names the kernel in profiles.  Synchronises. */
+int rt_debug_walk_rays(rt_ctx*, const float* rays8, uint32_t n, int variant, int refill, uint32_t repeats, float* out_hits4, float* out_ms);
+
 /* ---- host-side helpers (CPU; mirror the reference's host code that stays on the host) ------------ */
 /* Camera (Camera.cpp:11-19,122-132): glm::perspectiveFov / lookAt / inverse in glm's evaluation order. */
 void rt_host_camera_default_forward(float fwd[3]);

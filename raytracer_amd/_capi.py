@@ -23,6 +23,7 @@ EXPORTS = [
     "rt_render_frames", "rt_render_spheres_noalloc", "rt_render_spheres_noalloc_setup", "rt_resolve", "rt_reset_accum", "rt_sync", "rt_read_image", "rt_map_image", "rt_map_image_pipelined", "rt_read_accum", "rt_set_record_ids",
     "rt_read_primary_ids", "rt_read_ray_dirs", "rt_set_stats", "rt_read_counters", "rt_reset_counters", "rt_read_wave_clock",
     "rt_get_kernel_time", "rt_reset_kernel_time", "rt_set_kernel_timing", "rt_device_accum", "rt_device_image",
+    "rt_debug_dump_rays", "rt_debug_walk_rays",
     "rt_group_create", "rt_group_destroy", "rt_group_size", "rt_group_ctx", "rt_group_last_error", "rt_group_render_tiles",
     "rt_group_render_samples", "rt_group_read_accum", "rt_group_issue_overlap",
     "rt_host_camera_default_forward", "rt_host_camera_matrices", "rt_host_kd_build", "rt_host_kd_flat", "rt_host_kd_free",
@@ -101,6 +102,8 @@ def lib():
         "rt_set_stats": ([vp, C.c_int], C.c_int), "rt_read_counters": ([vp, vp], C.c_int),
         "rt_reset_counters": ([vp], C.c_int), "rt_set_kernel_timing": ([vp, u32], C.c_int), "rt_read_wave_clock": ([vp, vp, u32, vp], C.c_int), "rt_get_kernel_time": ([vp, vp], C.c_int),
         "rt_reset_kernel_time": ([vp], C.c_int), "rt_device_accum": ([vp], vp), "rt_device_image": ([vp], vp),
+        "rt_debug_dump_rays": ([vp, u32, vp, u32, vp], C.c_int),
+        "rt_debug_walk_rays": ([vp, vp, u32, C.c_int, C.c_int, u32, vp, vp], C.c_int),
         "rt_group_create": ([vp, C.c_int], vp), "rt_group_destroy": ([vp], None), "rt_group_size": ([vp], C.c_int),
         "rt_group_ctx": ([vp, C.c_int], vp), "rt_group_last_error": ([vp], C.c_char_p),
         "rt_group_render_tiles": ([vp, u32, u32], C.c_int), "rt_group_render_samples": ([vp, u32, u32], C.c_int),

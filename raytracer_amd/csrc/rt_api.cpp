@@ -35,6 +35,9 @@ extern "C" hipError_t rt_launch_sum_resolve(const RtParams* p, unsigned frame_in
 extern "C" hipError_t rt_launch_parked_rays(const RtParams* p, int stats, hipStream_t s);
 extern "C" hipError_t rt_launch_resolve(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
 extern "C" hipError_t rt_launch_aa(const RtParams* p, unsigned frame_index, unsigned gx, unsigned gy, hipStream_t s);
+extern "C" hipError_t rt_launch_probe_walk(const RtParams* p, const float4* rays, uint32_t n, uint32_t* next, int refill, int variant,
+                                           unsigned grid, float4* out, hipStream_t s);
+extern "C" hipError_t rt_probe_walk_occupancy(int* blocks_per_cu);
 extern "C" hipError_t rt_static_setup(int device);               // rt_static.hip: per-device address of its static working memory
 
 namespace {
@@ -174,6 +177,10 @@ struct rt_ctx {
     uint32_t n_columns = 0;              // host copy of the count (read back once per change)
     uint32_t n_refs = 0;
 
+    // experiments: rays the counting kernels append while rt_debug_dump_rays runs (RtParams::ray_dump)
+    DevBuf<float4> d_ray_dump; DevBuf<uint32_t> d_ray_dump_count;
+    bool dump_on = false;
+
     int n_cus = 0;
     int blocks_per_cu[12] = {};          // trace-kernel residency per (mode, stats, ordered), queried once
     float root_center[3] = {0.0f, 0.0f, 0.0f};                       // see RtParams
@@ -294,6 +301,7 @@ void fill_params(rt_ctx* c, RtParams& p, uint32_t frame_first, uint32_t n_frames
     p.park_keys = c->d_park_keys.ptr; p.park_boxes = c->d_park_boxes.ptr; p.park_queue = c->d_park_queue.ptr;
     p.park_queue_count = c->d_park_queue_count.ptr; p.park_queue_cap = rt_ctx::kParkQueueCap;
     p.ray_slot = -1; p.resume = 0; p.park_min_nodes = c->park_min_nodes;
+    if (c->dump_on) { p.ray_dump = c->d_ray_dump.ptr; p.ray_dump_count = c->d_ray_dump_count.ptr; p.ray_dump_cap = (uint32_t)(c->d_ray_dump.count / 2); }
     p.first_hits = nullptr; p.first_hit_mode = 0u;
     // (measured: mesh-only scenes with a large tree, and their launches of several Renders, gain 2-4 % from the shorter slices; with
     // spheres and mesh together the lanes that leave a slice run the sphere loop and the shading next, and the fuller batches of
@@ -449,7 +457,7 @@ void rt_destroy(rt_ctx* c)
         if (c->ev_stop[i]) (void)hipEventDestroy(c->ev_stop[i]);
         if (c->ev_pre[i]) (void)hipEventDestroy(c->ev_pre[i]);
     }
-    c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release();
+    c->d_slots.release(); c->d_image_back.release(); c->d_first_hits.release(); c->d_ray_dump.release(); c->d_ray_dump_count.release();
     c->d_unit_empty.release(); c->d_unit_list.release(); c->d_unit_counts.release(); c->d_unit_entry.release(); c->d_unit_block.release();
     for (int i = 0; i < rt_ctx::UP_RING; ++i) {
         if (c->up_done[i]) (void)hipEventDestroy(c->up_done[i]);
@@ -1595,6 +1603,71 @@ __attribute__((visibility("hidden"))) int rt_internal_resolve_from(rt_ctx* c, co
     c->latest_in_back = false; c->unsettle();
     LAUNCH_TRY(c, rt_launch_resolve(&p, frame_index, gx, gy, c->stream));
     if (c->settings.anti_aliasing) LAUNCH_TRY(c, rt_launch_aa(&p, frame_index, gx, gy, c->stream));
+    return RT_OK;
+}
+
+// ---- experiments (see include/rt_mi355x.h) ----
+int rt_debug_dump_rays(rt_ctx* c, uint32_t frame_index, float* out_rays8, uint32_t cap, uint32_t* n_out)
+{
+    if (!c || !out_rays8 || !cap || !n_out) return RT_E_ARG;
+    if (c->settings.scene_mode == RT_SCENE_SPHERES) return fail(c, RT_E_STATE, "rt_debug_dump_rays: a scene with a tree");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, c->d_ray_dump.resize(2 * (size_t)cap));
+    HIP_TRY(c, c->d_ray_dump_count.resize(1));
+    HIP_TRY(c, hipMemsetAsync(c->d_ray_dump_count.ptr, 0, sizeof(uint32_t), c->stream));
+    const bool stats = c->stats;
+    c->stats = true; c->dump_on = true;
+    const int rc = rt_render(c, frame_index);
+    c->stats = stats; c->dump_on = false;
+    if (rc) return rc;
+    uint32_t n = 0;
+    HIP_TRY(c, hipMemcpyAsync(&n, c->d_ray_dump_count.ptr, sizeof n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *n_out = n;
+    if (n > cap) n = cap;
+    HIP_TRY(c, hipMemcpy(out_rays8, c->d_ray_dump.ptr, (size_t)n * 8 * sizeof(float), hipMemcpyDeviceToHost));
+    c->d_ray_dump.release();
+    return RT_OK;
+}
+
+int rt_debug_walk_rays(rt_ctx* c, const float* rays8, uint32_t n, int variant, int refill, uint32_t repeats, float* out_hits4, float* out_ms)
+{
+    if (!c || !rays8 || !n || !repeats || !out_ms) return RT_E_ARG;
+    if (!c->n_nodes) return fail(c, RT_E_STATE, "rt_debug_walk_rays: no tree");
+    DeviceGuard g(c->device);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    DevBuf<float4> d_rays, d_out; DevBuf<uint32_t> d_next;
+    struct Free { DevBuf<float4>&a, &b; DevBuf<uint32_t>& n; ~Free() { a.release(); b.release(); n.release(); } } freer{d_rays, d_out, d_next};
+    HIP_TRY(c, d_rays.resize(2 * (size_t)n)); HIP_TRY(c, d_out.resize(n)); HIP_TRY(c, d_next.resize(1));
+    HIP_TRY(c, hipMemcpy(d_rays.ptr, rays8, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
+    RtParams p; fill_params(c, p, 1, 1);
+    unsigned grid = (n + 255u) / 256u;
+    if (refill) {
+        int per_cu = 0;
+        HIP_TRY(c, rt_probe_walk_occupancy(&per_cu));
+        const unsigned full = (unsigned)c->n_cus * (unsigned)(per_cu < 1 ? 1 : per_cu);
+        if (grid > full) grid = full;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+    double total = 0.0;
+    int rc = RT_OK;
+    for (uint32_t r = 0; r <= repeats && rc == RT_OK; ++r) {             // (the first launch warms the caches and is not counted)
+        hipError_t e = hipMemsetAsync(d_next.ptr, 0, sizeof(uint32_t), c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) e = rt_launch_probe_walk(&p, d_rays.ptr, n, d_next.ptr, refill, variant, grid, d_out.ptr, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.0f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(c, RT_E_HIP, "rt_debug_walk_rays: %s", hipGetErrorString(e));
+        if (r) total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *out_ms = (float)(total / repeats);
+    if (out_hits4) HIP_TRY(c, hipMemcpy(out_hits4, d_out.ptr, (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

@@ -230,5 +230,9 @@ struct RtParams {
     uint32_t  resume;                        // trace kernel: 0 = draw units; 1 = continue the paths of the resume list (may park again);
                                              // 2 = the same, but rays the tree cannot prune are walked by their wave
     uint32_t  resume_lanes;                  // ... by the first resume_lanes lanes of each wave, one path each (path w * resume_lanes + lane)
+    // Experiments (the counting kernels only): every ray that starts a walk is appended here as { origin, bounce } { direction, pixel }
+    float4*   ray_dump;
+    uint32_t* ray_dump_count;
+    uint32_t  ray_dump_cap;
     float4   sph_inline[RT_INLINE_SPHERES]; // first spheres { center.xyz, radius^2 } by value
 };

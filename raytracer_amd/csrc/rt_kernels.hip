@@ -2096,6 +2096,20 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     // its entry: the walk is over before it starts (a trip would read whatever lies behind the array as a node).
                     if (wnode >= end) phase = PH_SHADE;
                     else if (PLAIN && !(p.slab_plain != 0u && slab_plain_ray(s.O, winvD))) phase = PH_REDO;     // (see PLAIN)
+                    if (STATS && p.ray_dump) {              // experiments: the rays that walk, in the order the waves start them
+                        const unsigned long long m = __ballot(phase == PH_WALK);
+                        if (phase == PH_WALK) {
+                            const int leader = __ffsll((long long)m) - 1;
+                            uint32_t base = 0;
+                            if ((int)lane == leader) base = atomicAdd(p.ray_dump_count, (uint32_t)__popcll(m));
+                            base = (uint32_t)__shfl((int)base, leader);
+                            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (at < p.ray_dump_cap) {
+                                p.ray_dump[2 * (size_t)at] = make_float4(s.O.x, s.O.y, s.O.z, __uint_as_float(s.bounce));
+                                p.ray_dump[2 * (size_t)at + 1] = make_float4(s.D.x, s.D.y, s.D.z, __uint_as_float(pixel));
+                            }
+                        }
+                    }
                 }
             } else if (begin && phase == PH_BEGIN) {
                 phase = PH_SHADE;                           // no bounces at all: the path ends with its initial colour
@@ -2501,6 +2515,113 @@ __global__ __launch_bounds__(256) void rt_aa_kernel(RtParams p, uint32_t frame_i
         }
     if (weight == 0.0f) return;
     p.image[y * p.width + x] = resolve_px(acc, weight * (float)frame_index, p.use_ace);
+}
+
+// ---- experiment: a list of rays walked front to back, one lane per ray ----------------------------------------------------------
+// The walk of the timed kernels (the node array of the ray's sign pattern, the short box test, up to three node steps or two
+// record steps from one read of six float4, pruning at the closest hit plus the near-tie distance) applied to rays given as a
+// list -- in whatever order the caller put them.  What a sorted order of scattered rays could buy is measured with this: the
+// same rays in the order the waves of the trace kernel started them and sorted by direction octant and origin cell.
+// refill = 0: ray i belongs to thread i; refill = 1: a persistent grid whose lanes draw the next rays of the list, sixteen at
+// least at a time, as their walks end.  VARIANT only names the launch (profiles tell the two orders apart by it).
+// out[i] = { t, u, v, bits(triangle) } (-1: no hit, -3: a ray the short box test is not exact for, not walked).
+template <int VARIANT>
+__global__ __launch_bounds__(256) void rt_probe_walk_kernel(RtParams p, const float4* __restrict__ rays, uint32_t n, uint32_t* next, int refill,
+                                                            float4* __restrict__ out)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t end = p.n_nodes;
+    bool walking = false, exhausted = false;
+    uint32_t ray = 0;
+    F3 O = f3(0.0f, 0.0f, 0.0f), D = O, invD = O;
+    Hit th; th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
+    uint32_t wnode = 0, wrec = RT_NO_REC, wbest = RT_NO_REC, woct = 0;
+    float wtol = 0.0f, wprune = FLT_MAX;
+    auto begin = [&](uint32_t i) {
+        ray = i;
+        const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+        O = f3(a.x, a.y, a.z); D = f3(b.x, b.y, b.z);
+        invD = f3(1.0f / D.x, 1.0f / D.y, 1.0f / D.z);
+        woct = (D.x < 0.0f ? 1u : 0u) | (D.y < 0.0f ? 2u : 0u) | (D.z < 0.0f ? 4u : 0u);
+        th.t = FLT_MAX; th.id = -1; th.u = 0.0f; th.v = 0.0f;
+        wnode = 0; wrec = RT_NO_REC; wbest = RT_NO_REC; wprune = FLT_MAX;
+        const float bx = (fabsf(O.x - p.root_center[0]) + p.tie_box[0]) * fabsf(invD.x);
+        const float by = (fabsf(O.y - p.root_center[1]) + p.tie_box[1]) * fabsf(invD.y);
+        const float bz = (fabsf(O.z - p.root_center[2]) + p.tie_box[2]) * fabsf(invD.z);
+        wtol = fmaxf(bx, fmaxf(by, bz)) * p.tie_ulp + p.tie_abs;
+        walking = true;
+        if (!(p.slab_plain != 0u && slab_plain_ray(O, invD)) || end == 0u) {
+            out[i] = make_float4(FLT_MAX, 0.0f, 0.0f, __uint_as_float((uint32_t)-3));
+            walking = false;
+        }
+    };
+    if (!refill) {
+        const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+        if (i < n) begin(i);
+        exhausted = true;
+    }
+    for (;;) {
+        if (!exhausted) {
+            const unsigned long long idle = __ballot(!walking);
+            const uint32_t want = (uint32_t)__popcll(idle);
+            if (want >= 16u) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next, want);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint32_t mine = base + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+                if (!walking && mine < n) begin(mine);
+                if (base + want >= n) exhausted = true;
+            }
+        }
+        if (__ballot(walking) == 0ull) { if (exhausted) break; else continue; }
+        if (walking) {
+            const bool at_node = wrec == RT_NO_REC;
+            const float4* a = at_node ? p.nodes + 2 * ((size_t)woct * (size_t)p.n_nodes + wnode) : p.leafrecs + 3 * (size_t)wrec;
+            const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5];
+            auto node_step = [&](float4 n0, float4 n1) -> bool {
+                float tNear;
+                const bool box = slab_test_t<true>(n0, n1, O, invD, tNear);
+                const bool descend = box && !(tNear > wprune);
+                const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
+                if (descend && leaf_first == RT_LEAF_INTERIOR) { wnode = wnode + 1; return true; }
+                wnode = __float_as_uint(n0.w);
+                if (descend && leaf_first >= 0) wrec = (uint32_t)leaf_first;
+                return false;
+            };
+            auto rec_step = [&](float4 r0, float4 r1, float4 r2) -> bool {
+                const uint32_t tag = __float_as_uint(r2.y);
+                float tt, u, v;
+                if (tri_test_t<true>(r0, r1, r2, O, D, tt, u, v)) {
+                    if (tt < th.t || (tt == th.t && th.id >= 0 && wrec < wbest)) {
+                        th.t = tt; th.id = (int32_t)(tag & 0x7FFFFFFFu); th.u = u; th.v = v; wbest = wrec;
+                        wprune = tt + (wtol + p.tie_rel * tt);
+                    }
+                }
+                const bool more = (tag & 0x80000000u) == 0u;
+                wrec = more ? wrec + 1u : RT_NO_REC;
+                return more;
+            };
+            if (at_node) { if (node_step(q0, q1) && node_step(q2, q3)) node_step(q4, q5); }
+            else { if (rec_step(q0, q1, q2)) rec_step(q3, q4, q5); }
+            if (wrec == RT_NO_REC && wnode >= end) {
+                out[ray] = make_float4(th.t, th.u, th.v, __uint_as_float((uint32_t)th.id));
+                walking = false;
+            }
+        }
+    }
+}
+
+extern "C" hipError_t rt_launch_probe_walk(const RtParams* p, const float4* rays, uint32_t n, uint32_t* next, int refill, int variant,
+                                           unsigned grid, float4* out, hipStream_t s)
+{
+    if (variant) hipLaunchKernelGGL(rt_probe_walk_kernel<1>, dim3(grid), dim3(256), 0, s, *p, rays, n, next, refill, out);
+    else hipLaunchKernelGGL(rt_probe_walk_kernel<0>, dim3(grid), dim3(256), 0, s, *p, rays, n, next, refill, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rt_probe_walk_occupancy(int* blocks_per_cu)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, rt_probe_walk_kernel<0>, 256, 0);
 }
 
 // ---- launchers (called from rt_api.cpp) -----------------------------------------------------------------------------
