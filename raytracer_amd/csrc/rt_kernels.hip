@@ -2294,8 +2294,13 @@ __global__ __launch_bounds__(RT_SPHERE_BLOCK) __attribute__((amdgpu_num_sgpr(80)
     sphere_body<STATS, LDS_SCENE>(p);
 }
 
+#ifdef RT_TREE_WAVES
+#define RT_TREE_OCCUPANCY __attribute__((amdgpu_waves_per_eu(RT_TREE_WAVES, RT_TREE_WAVES)))
+#else
+#define RT_TREE_OCCUPANCY
+#endif
 template <int MODE, bool STATS, bool ORDERED>
-__global__ __launch_bounds__(RT_TREE_BLOCK) void rt_trace_kernel(RtParams p)
+__global__ __launch_bounds__(RT_TREE_BLOCK) RT_TREE_OCCUPANCY void rt_trace_kernel(RtParams p)
 {
     // tree scenes keep the closest-hit lookups in HBM: these kernels are bound by registers (waves per SIMD), not by those loads
     tree_body<MODE, STATS, ORDERED>(p);
