@@ -4,7 +4,9 @@ huge size, cameras inside spheres, roughness beyond 1, refraction indices below 
 albedo 0, meshes next to or around the camera, zero or one bounce -- rendered by the library and by the oracle; primary ids,
 accumulation and image must agree bit for bit.  python tools/fuzz_parity.py [cases] [seed]
 FUZZ_WIDE=1 widens the draw (larger meshes, frames of 1 x 1 to 130 x 70 pixels); the default draw stays as it is so that a seed
-keeps naming the same scenes.  Meant to run against a library built with -DRT_CHECKED=1 (tools/build_variant.sh), in which a
+keeps naming the same scenes.  FUZZ_MOVES=1 also moves the camera between the launches of about half the cases (a turn, a step
+forward that keeps the centre column's direction.x == +0, a step sideways, the same pose sent again) while the accumulation goes
+on: the per-view data -- ray directions, column rays, unit lists, entry nodes, kept first hits -- is rebuilt in the middle of it.  Meant to run against a library built with -DRT_CHECKED=1 (tools/build_variant.sh), in which a
 state machine that leaves its arrays is reported as an error instead of faulting the GPU."""
 import os, sys
 import numpy as np
@@ -18,6 +20,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 pick = lambda *xs: xs[rng.integers(len(xs))]
 wide = bool(os.environ.get("FUZZ_WIDE"))
+moves = bool(os.environ.get("FUZZ_MOVES"))
 
 
 def random_materials(n):
@@ -94,6 +97,23 @@ for case in range(n_cases):
             elif k == 4: dirs[px] = np.float32(pick(1.0, -1.0)) * np.eye(3, dtype=np.float32)[rng.integers(3)]
             elif k == 5: dirs[px, 0] = np.float32(0.0); dirs[px, 1] = np.float32(-0.0)
             else: dirs[px] = rng.normal(size=3).astype(np.float32)
+    # the camera of every launch: the first one's, unless FUZZ_MOVES moves it in between
+    poses = [(cam.GetPosition().copy(), cam.GetDirection().copy())] * frames
+    if moves and not host_dirs and rng.random() < 0.5:
+        poses = [poses[0]]
+        for _ in range(frames - 1):
+            pos, fwd = poses[-1]
+            k = int(rng.integers(5))
+            if k == 0: pass                                                                                   # the same pose, sent again
+            elif k == 1: pos = (pos + fwd * np.float32(pick(0.01, 0.3, -0.2))).astype(np.float32)                # along the view direction
+            elif k == 2: pos = (pos + np.array([pick(0.05, -0.4), 0.0, 0.0], np.float32)).astype(np.float32)      # sideways
+            elif k == 3:
+                a = np.float32(pick(0.002, 0.3, -1.0)); c_, s_ = np.float32(np.cos(a)), np.float32(np.sin(a))
+                fwd = np.array([fwd[0] * c_ + fwd[2] * s_, fwd[1], -fwd[0] * s_ + fwd[2] * c_], np.float32)        # a turn about the vertical axis
+            else:
+                pos = (rng.normal(size=3) * 2.0).astype(np.float32); pos[1] += np.float32(1.0)
+            poses.append((pos, fwd))
+    moved = len(set((p_.tobytes(), f_.tobytes()) for p_, f_ in poses)) > 1
     acc = np.zeros((h * w, 3), np.float32); img = np.zeros((h * w, 4), np.float32); ids = np.zeros(h * w, np.int32)
     cnt = orc.Counters()
     ost = orc.Settings(1, mode, int(use_ace), int(aa), bounces)
@@ -101,6 +121,9 @@ for case in range(n_cases):
     try:
         f = 1
         for _launch in range(frames):
+            if moved:
+                cam.SetPose(*poses[_launch]); cam.OnResize(w, h)
+                dirs = orc.ray_dirs(cam.GetInverseProjection(), cam.GetInverseView(), w, h)
             for _k in range(per_launch):
                 osc.render_frame(ost, cam.GetPosition(), dirs, w, h, f, acc, img, seed=seed, primary_ids=ids if f == 1 else None, counters=cnt, nthreads=8)
                 f += 1
@@ -112,10 +135,13 @@ for case in range(n_cases):
             if host_dirs:
                 rr.upload(scene, cam); rr.set_ray_dirs(dirs)
             for _launch in range(frames):
+                if moved:
+                    cam.SetPose(*poses[_launch]); cam.OnResize(w, h)
                 rr.Render(scene, cam, frames=per_launch)
+                if moved and _launch == 0: first_ids = rr.read_primary_ids().ravel().copy()        # (ids are those of frame index 1)
             rows = np.arange(h) if world == 1 else rtd.band_rows(h, rank, world)
             px = (rows[:, None] * w + np.arange(w)[None, :]).ravel()
-            g_ids[px] = rr.read_primary_ids().ravel()[px]; g_acc[px] = rr.read_accum().reshape(-1, 3)[px]; g_img[px] = rr.GetImage().data.reshape(-1, 4)[px]
+            g_ids[px] = (first_ids if moved else rr.read_primary_ids().ravel())[px]; g_acc[px] = rr.read_accum().reshape(-1, 3)[px]; g_img[px] = rr.GetImage().data.reshape(-1, 4)[px]
             g_rays += rr.read_counters().rays
             if world > 1: del rr
         if world > 1 and aa: g_rays = cnt.rays                   # (under a tile split with the filter on, the rows bordering a band are traced twice)
@@ -127,8 +153,8 @@ for case in range(n_cases):
     except Exception as e:                                   # an error from the library (a refused scene, a failed GPU call) ends the probe:
         print("ERROR    case %d: %s: %s" % (case, type(e).__name__, e), flush=True)       # nothing more is started on the GPU after it
         sys.exit(2)
-    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d, ranks %d" % (
-        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs, world)
+    desc = "case %d: mode %d, %d spheres, %d materials, %dx%d, %d bounces, %d launches of %d, ace %d, aa %d, order %d, kept hits %d, host directions %d, ranks %d, camera moves %d" % (
+        case, mode, len(scene.spheres), n_mats, w, h, bounces, frames, per_launch, use_ace, aa, order, reuse, host_dirs, world, moved)
     if bad:
         failures += 1
         print("MISMATCH", desc, "|", "; ".join(bad), flush=True)
