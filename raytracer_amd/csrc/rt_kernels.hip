@@ -70,6 +70,21 @@ __device__ __forceinline__ float rcp_unscaled(float d)
     return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r, q);
 }
 
+// a / d, correctly rounded, for operands of moderate size: the compiler's expansion of the fp32 division (reciprocal estimate, one
+// Newton step on it, quotient, two residual corrections) with the operand scaling and the special-case pass left out.  Neither
+// does anything while a is zero or 2^-100 <= |a| <= 2^100, 2^-100 <= |d| <= 2^100 and the quotient stays within those bounds as
+// well: every intermediate value is then a normal number, and scaling by powers of two would change no rounding.  The callers
+// prove the ranges.  (8 instructions instead of 11 + the waits for the scaling's condition codes, and the reciprocal's part is
+// shared between quotients with the same divisor.)
+__device__ __forceinline__ float div_unscaled(float a, float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    float q = a * r;
+    q = __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, a), r, q);
+}
+
 __device__ __forceinline__ float rsqrt_rn(float x)
 {
 #if RT_FAST_RSQRT
@@ -166,7 +181,7 @@ __device__ __forceinline__ float pow_inv24(float x)
     int e = (int)(ux >> 23) - 127;
     float m = __uint_as_float((ux & 0x007FFFFFu) | 0x3F800000u);
     if (m > 1.41421354f) { m = m * 0.5f; e = e + 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
+    float s = div_unscaled(m - 1.0f, m + 1.0f);   // m lies in (0.707, 1.4143] whatever x is: |m - 1| is 0 or at least 2^-24, m + 1 in (1.7, 2.42)
     float s2 = s * s;
     float p = 0.111111111f * s2;
     p = p + 0.142857143f;
@@ -203,11 +218,14 @@ __device__ __forceinline__ float pow_inv24(float x)
 // ---- tone map: Util::ACESFilm + LinearToSRGB (Renderer.h:57-98) ---------------------------------------------------
 __device__ __forceinline__ float clamp01(float x) { return sel_min(sel_max(x, 0.0f), 1.0f); }
 
+// PLAIN: x is zero or 2^-72 <= x <= 2^40 (see resolve_px): numerator and denominator of the ACES curve then lie within
+// [2^-78, 2^82] and [0.14, 2^82], their quotient within [2^-75, 1.04].
+template <bool PLAIN>
 __device__ __forceinline__ float tonemap1(float x)
 {
     float num = x * (2.51f * x + 0.03f);
     float den = x * (2.43f * x + 0.59f) + 0.14f;
-    float c = clamp01(num / den);          // ACESFilm
+    float c = clamp01(PLAIN ? div_unscaled(num, den) : num / den);          // ACESFilm
     c = clamp01(c);                        // LinearToSRGB's own clamp
     float hi = pow_inv24(c) * 1.055f - 0.055f;
     float lo = c * 12.92f;
@@ -215,10 +233,21 @@ __device__ __forceinline__ float tonemap1(float x)
     return hi * (1.0f - a) + lo * a;
 }
 
+// Sums that are zero or between 2^-40 and 2^40 (every sum of a sane scene), divided by a frame count between 1 and 2^32, take the
+// short form of the division here and in the tone map; a wave that holds any other sum -- negative, huge, tiny, NaN -- takes the
+// general forms for all its pixels.  Same bits either way.
 __device__ __forceinline__ float4 resolve_px(F3 acc, float div, int use_ace)
 {
-    float r = acc.x / div, g = acc.y / div, b = acc.z / div;
-    if (use_ace) { r = tonemap1(r); g = tonemap1(g); b = tonemap1(b); }
+    auto tame = [](float a) { return a == 0.0f || (a >= 0x1p-40f && a <= 0x1p40f); };
+    const bool plain = tame(acc.x) && tame(acc.y) && tame(acc.z) && div >= 1.0f && div <= 0x1p32f;
+    float r, g, b;
+    if (__ballot(!plain) == 0ull) {
+        r = div_unscaled(acc.x, div); g = div_unscaled(acc.y, div); b = div_unscaled(acc.z, div);
+        if (use_ace) { r = tonemap1<true>(r); g = tonemap1<true>(g); b = tonemap1<true>(b); }
+    } else {
+        r = acc.x / div; g = acc.y / div; b = acc.z / div;
+        if (use_ace) { r = tonemap1<false>(r); g = tonemap1<false>(g); b = tonemap1<false>(b); }
+    }
     return make_float4(r, g, b, 1.0f);
 }
 
