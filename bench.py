@@ -149,6 +149,18 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
             oscene.render_frame(st, cam.GetPosition(), dirs, w, h, f, acc, img, counters=cnt, nthreads=nthreads, row_step=step)
         return cnt.rays, time.perf_counter() - t0
 
+    # how the restatement compares with the reference's own objects (measured where they can be built: the build container)
+    port_vs_reference = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r3_reference_vs_oracle_cpu_timing.json")) as f:
+            t = json.loads(f.read().strip().splitlines()[0])
+        port_vs_reference = {"oracle_over_reference_time": t["oracle_over_reference_time"], "reference_Mrays_s_one_thread": t["reference_Mrays_s"],
+                             "oracle_Mrays_s_one_thread": t["oracle_Mrays_s"], "rays": t["rays"], "same_hits_and_t_bits": t["same_hits_and_t_bits"],
+                             "what": "KDTreeCPU::intersect of the reference's unmodified objects (oracle/_ref) against the oracle's restatement on the same "
+                                     "primary rays of the 69,938-triangle mesh, one thread each, in the build container (tools/ref_vs_oracle_timing.py); "
+                                     "committed, not measured in this run"}
+    except (OSError, ValueError, KeyError, IndexError):
+        pass
     rays, dt = run(threads, budget_frames, row_step)
     one_step = row_step * (16 if big else 8)                     # the one-thread leg sees an eighth (a sixteenth) of the rows of one frame
     rays1, dt1 = run(1, 1, one_step)
@@ -156,7 +168,7 @@ def cpu_baseline(cfg, scene, cam, budget_frames):
             "host_cpus_visible": os.cpu_count(),
             "sample": "%d frame(s) of the same %dx%d workload%s, oracle (CPU restatement, hash RNG), %.1f s wall"
                       % (budget_frames, w, h, "" if row_step == 1 else ", every %dth row" % row_step, dt),
-            "ms_per_frame_extrapolated": dt / budget_frames * 1e3 * row_step,
+            "ms_per_frame_extrapolated": dt / budget_frames * 1e3 * row_step, "port_vs_reference": port_vs_reference,
             "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
                            "sample": "1 frame, every %dth row, %.1f s wall" % (one_step, dt1),
                            "ms_per_frame_extrapolated": dt1 * 1e3 * one_step}}

@@ -1177,6 +1177,21 @@ __device__ __forceinline__ bool reach_ray(const RtParams& p, F3& O, F3& D, uint3
     return true;
 }
 
+// Counting kernels: *dst += weight x (threads of this 256-thread workgroup with `flag`), one atomic per workgroup.  Every thread of the
+// workgroup must call it.  (One atomic per wave onto the same word made the counting passes of a 10 M-triangle tree four times as
+// long as the passes themselves.)
+__device__ __forceinline__ void block_count_add(bool flag, unsigned long long* dst, uint32_t weight)
+{
+    __shared__ uint32_t wave_n[4];
+    const uint32_t n = (uint32_t)__popcll(__ballot(flag));
+    if ((threadIdx.x & 63u) == 0u) wave_n[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t sum = (wave_n[0] + wave_n[1]) + (wave_n[2] + wave_n[3]);
+        if (sum) atomicAdd(dst, (unsigned long long)sum * weight);
+    }
+}
+
 __global__ __launch_bounds__(256) void rt_column_reach_max_kernel(RtParams p)
 {
     __shared__ uint32_t wave_max[4];
@@ -1263,10 +1278,7 @@ __global__ __launch_bounds__(256) void rt_column_reach_mark_kernel(RtParams p, i
     if (lane == 0u && (j & ~63u) < p.n_nodes) p.reached[j >> 6] = entered;
     // a visited box with a real t_near could be pruned by the closest t so far: then the visited set is not fixed
     if (__ballot(visited && box && tNear == tNear) != 0ull && lane == 0u) atomicOr(p.ray_slot < 0 ? p.column_flags : (uint32_t*)p.park_info + 2 * RT_PARK_FAMILIES + p.ray_slot, 1u);
-    if (stats) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(visited));
-        if (lane == 0u && n) atomicAdd(&p.column_stats[0], (unsigned long long)n * count);  // every ray of the family visits these nodes
-    }
+    if (stats) block_count_add(visited, &p.column_stats[0], count);        // every ray of the family visits these nodes
 }
 
 // Parked rays (direction.x == 0, see tree_body).  With an infinite inverse in x the slab test hits every box on one side of
@@ -1439,10 +1451,7 @@ __global__ __launch_bounds__(256) void rt_park_filter_kernel(RtParams p, int sta
     const uint32_t r = blockIdx.x * 256u + threadIdx.x;
     bool use = false;
     if (r < p.n_refs) { const uint32_t leaf = p.rec_leaf[r]; use = ((p.reached[leaf >> 6] >> (leaf & 63u)) & 1ull) != 0ull; }
-    if (stats) {
-        const uint32_t n = (uint32_t)__popcll(__ballot(use));
-        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * count);       // the tests the reference makes
-    }
+    if (stats) block_count_add(use, &p.column_stats[1], count);            // the tests the reference makes
     if (!use) return;
     const float4 r0 = p.leafrecs[3 * (size_t)r], r1 = p.leafrecs[3 * (size_t)r + 1], r2 = p.leafrecs[3 * (size_t)r + 2];
     const F3 v0 = f3(r0.x, r0.y, r0.z), e1 = f3(r0.w, r1.x, r1.y), e2 = f3(r1.z, r1.w, r2.x);
@@ -1537,11 +1546,7 @@ __global__ __launch_bounds__(256) void rt_column_filter_kernel(RtParams p, int s
         use = ((p.reached[leaf >> 6] >> (leaf & 63u)) & 1ull) != 0ull;
         if (use) { r0 = p.leafrecs[3 * (size_t)r]; r1 = p.leafrecs[3 * (size_t)r + 1]; r2 = p.leafrecs[3 * (size_t)r + 2]; }
     }
-    const unsigned long long any = __ballot(use);
-    if (stats) {
-        const uint32_t n = (uint32_t)__popcll(any);
-        if ((threadIdx.x & 63u) == 0u && n) atomicAdd(&p.column_stats[1], (unsigned long long)n * count);   // the tests the reference makes
-    }
+    if (stats) block_count_add(use, &p.column_stats[1], count);            // the tests the reference makes
     if (!use) return;
     const F3 O = f3(p.cam_pos[0], p.cam_pos[1], p.cam_pos[2]);
     const ColumnTri c = column_tri(r0, r1, r2, O);
