@@ -198,9 +198,10 @@ int rt_group_issue_overlap(const rt_group*);
    context's stream and the call returns without waiting for it, with one exception: in a tree of 2^18 nodes or more (2^12 with
    spheres and mesh together) the call waits for its trace kernel to finish, because what follows it depends on one word the
    kernel leaves behind -- the number of bounce rays with direction.x == 0 it handed to whole-chip kernels; the passes after
-   that (those rays' hits, the sums, the image) are again only queued.  Nothing else waits for the device once frame size,
-   scene and tree are in place: a new camera costs kernels, not round trips (the per-view counts the host keeps for
-   rt_read_counters come back behind the kernels). */
+   that (those rays' hits, the sums, the image) are again only queued.  Once frame size, scene and tree are in place, the only
+   other wait is for one word per NEW view of a tree scene (how many primary rays have direction.x == +0: it decides whether the
+   pre-pass for them is launched), taken while the kernels that classify the view's work units are still queued; the other
+   per-view counts, which the host keeps for rt_read_counters only, come back behind the kernels and are never waited for. */
 int rt_render(rt_ctx*, uint32_t frame_index);
 /* n consecutive Render calls (frame_index .. frame_index+n-1) with the scene, camera and settings of the moment; identical
    accumulation (the per-frame values are added in frame order), only the last frame's image is resolved.  Sphere scenes: one

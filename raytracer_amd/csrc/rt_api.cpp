@@ -977,8 +977,14 @@ int settle_view(rt_ctx* c, bool wait)
         pending = false;
         return 1;
     };
-    int r = arrived(c->columns_pending, c->ev_columns);
-    if (r < 0) return fail(c, RT_E_HIP, "waiting for the column count");
+    // (the column count of the view being set up is waited for at the one place that needs it, render_issue: `wait` is for the
+    // counts of a view that is being left, which arrived long ago)
+    int r = 0;
+    if (c->columns_pending) {
+        const hipError_t q = hipEventQuery(c->ev_columns);
+        if (q == hipSuccess) { c->columns_pending = false; r = 1; }
+        else if (q != hipErrorNotReady) return fail(c, RT_E_HIP, "waiting for the column count");
+    }
     if (r) { c->n_columns = c->h_view[0]; c->columns_known = true; }
     r = arrived(c->units_pending, c->ev_units);
     if (r < 0) return fail(c, RT_E_HIP, "waiting for the unit counts");
@@ -995,8 +1001,8 @@ int settle_view(rt_ctx* c, bool wait)
     return RT_OK;
 }
 
-// Column rays of the current directions/bands: slots into dirs[].w.  Their number comes back behind the kernels (rt_ctx::h_view);
-// until it has arrived the pre-pass is launched as if there were some (its kernels return at once when there are none).
+// Column rays of the current directions/bands: slots into dirs[].w.  Their number comes back behind the kernels (rt_ctx::h_view)
+// and is waited for in render_issue, once the unit classification has been queued as well.
 int ensure_columns(rt_ctx* c, RtParams& p)
 {
     // scratch for the per-block scans: one word per 256 pixels / 256 nodes / 256 slots, whichever is most
@@ -1238,7 +1244,13 @@ int render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending& L)
     const bool timed = c->timing_every != 0u && c->timing_count++ % c->timing_every == c->timing_every / 2u;
     const unsigned ev = c->ev_head % rt_ctx::EV_RING;
     c->tests_may_overflow = tree && !tri_tests_stay_finite(c);
-    // (until the number of column rays has arrived the pre-pass is launched as if there were some: its kernels return at once otherwise)
+    // Whether the view has column rays decides whether the pre-pass is launched (over a large tree even kernels that return at once
+    // cost more than the wait): the one word is waited for here, after the unit classification has been queued behind it, so the
+    // device has work while the host wakes up.  Once per view.
+    if (tree && c->columns_pending) {
+        HIP_TRY(c, hipEventSynchronize(c->ev_columns));
+        c->columns_pending = false; c->n_columns = c->h_view[0]; c->columns_known = true;
+    }
     const bool columns = tree && (!c->columns_known || c->n_columns) && !c->tests_may_overflow && (!reuse || store_first);     // (stored hits answer the column rays too)
     // Which triangle a column ray hits depends on the camera, the directions, the bands and the tree only: the pre-pass runs when
     // one of those changed and its result (the best hit per column ray) is kept.  The counting kernels always run it: their
