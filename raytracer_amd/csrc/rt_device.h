@@ -33,7 +33,16 @@
 #define RT_PARK_MIN_NODES_MIXED (1u << 12)   // ... and with spheres and mesh together, where such rays come by the hundred
 #define RT_PARK_WORDS 5            // float4 per parked path
 #define RT_MAX_LAUNCH_FRAMES 16    // tree scenes: Renders one launch can hold (a plane of per-pixel radiance slots each)
-#define RT_WALK_FETCH 6           /* float4 read per walk trip: up to three consecutive nodes or two leaf records */
+#define RT_WALK_FETCH 6           /* float4 read per walk trip at most: up to three consecutive nodes or two leaf records */
+#ifndef RT_TRIP_NODES
+#define RT_TRIP_NODES 2           /* node steps a lane makes from one read, while it keeps descending to the next node in memory (1..3) */
+#endif
+#ifndef RT_TRIP_RECS
+#define RT_TRIP_RECS 1            /* leaf records a lane tests from one read (1..2).  Measured (ms per Render / per frame at 16 Renders per launch,
+                                     70 k triangles | 10 M triangles | spheres + 10 M triangles): 3 + 2: 0.400 / 0.117 | 2.44 / 1.82 | 8.27 / 7.03;
+                                     2 + 2: 0.392 / 0.114 | 2.40 / 1.78 | 8.21 / 6.95; 2 + 1: 0.402 / 0.113 | 2.42 / 1.72 | 7.97 / 6.67;
+                                     1 + 1 and 3 + 1 are slower than 3 + 2.  Later steps of a trip run for the few lanes that kept descending */
+#endif
 #ifndef RT_NEAR_TIES
 #define RT_NEAR_TIES 1             /* 0 compiles the near-tie test and the repeat walk out (A/B measurements) */
 #endif

@@ -2205,16 +2205,20 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     }
                 }
                 if (phase == PH_WALK) {
-                    // One read of RT_WALK_FETCH float4 at the cursor per trip.  Descending goes to the next node in memory
-                    // and a leaf's records are consecutive, so the read holds the next two nodes / the next record as well:
-                    // up to three node steps or two record steps are made from it, which shortens the chain of dependent
-                    // loads that a long walk is.
+                    // One read at the cursor per trip.  Descending goes to the next node in memory (and a leaf's records are
+                    // consecutive), so the read holds the next node as well: up to RT_TRIP_NODES node steps (RT_TRIP_RECS record
+                    // steps) are made from it, which shortens the chain of dependent loads that a long walk is -- at the price
+                    // of instructions that run for the few lanes that kept descending (see rt_device.h for the measurements).
                     const bool at_node = wrec == RT_NO_REC;
                     // (the cursor is an index into arrays named by the kernel arguments, so these are global loads, not generic ones)
                     const float4* a = at_node ? p.nodes + 2 * ((size_t)woct * (size_t)p.n_nodes + checked(p, wnode, end, 1))
                                               : p.leafrecs + 3 * (size_t)checked(p, wrec, p.n_refs, 2);
-                    const float4 q0 = a[0], q1 = a[1], q2 = a[2], q3 = a[3], q4 = a[4], q5 = a[5];
-                    static_assert(RT_WALK_FETCH == 6, "the walk reads six float4 per trip");
+                    constexpr bool wide = RT_TRIP_NODES >= 3 || RT_TRIP_RECS >= 2, mid = RT_TRIP_NODES >= 2 || wide;
+                    const float4 q0 = a[0], q1 = a[1], q2 = a[2];
+                    float4 q3 = q0, q4 = q0, q5 = q0;
+                    if (mid) q3 = a[3];
+                    if (wide) { q4 = a[4]; q5 = a[5]; }
+                    static_assert(RT_WALK_FETCH == 6, "the walk reads up to six float4 per trip");
                     // returns true when the walk went down to the next node in memory
                     auto node_step = [&](float4 n0, float4 n1) -> bool {
                         wsteps++;
@@ -2248,9 +2252,12 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         return more;
                     };
                     if (at_node) {
-                        if (node_step(q0, q1) && node_step(q2, q3)) node_step(q4, q5);
+                        bool down = node_step(q0, q1);
+                        if (RT_TRIP_NODES >= 2 && down) down = node_step(q2, q3);
+                        if (RT_TRIP_NODES >= 3 && down) node_step(q4, q5);
                     } else {
-                        if (rec_step(q0, q1, q2)) rec_step(q3, q4, q5);
+                        const bool more = rec_step(q0, q1, q2);
+                        if (RT_TRIP_RECS >= 2 && more) rec_step(q3, q4, q5);
                     }
                     if (wrec == RT_NO_REC && wnode >= end) {
                         if (ORDERED && wflag) {
