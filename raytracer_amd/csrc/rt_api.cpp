@@ -214,6 +214,18 @@ int fail(rt_ctx* c, int code, const char* fmt, ...)
 // A kernel launch; with RT_DEBUG_SYNC=1 in the environment the stream is drained right after it, so that a fault is reported
 // with the launch that caused it instead of at some later call (debugging aid: every launch then costs a host round trip).
 static const bool g_debug_sync = [] { const char* e = getenv("RT_DEBUG_SYNC"); return e && *e && *e != '0'; }();
+// RT_STALL_MS=<ms>: host-side steps (waits, whole entry points) that take longer than that are reported on stderr
+static const double g_stall_ms = [] { const char* e = getenv("RT_STALL_MS"); return e ? atof(e) : 0.0; }();
+struct StallTimer {
+    const char* what; std::chrono::steady_clock::time_point t0;
+    explicit StallTimer(const char* w) : what(w) { if (g_stall_ms > 0.0) t0 = std::chrono::steady_clock::now(); }
+    ~StallTimer()
+    {
+        if (g_stall_ms <= 0.0) return;
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > g_stall_ms) fprintf(stderr, "[rt stall] %s: %.2f ms\n", what, ms);
+    }
+};
 #define LAUNCH_TRY(c, expr)                                                                           \
     do { HIP_TRY(c, expr);                                                                           \
          if (g_debug_sync) { hipError_t s_ = hipStreamSynchronize((c)->stream);                      \
@@ -1142,7 +1154,7 @@ int trace_issue(rt_ctx* c, RtParams& p, int mode, bool ordered, unsigned grid, h
 int trace_finish(rt_ctx* c, RtParams& p, int mode, bool ordered, bool parking)
 {
     if (!parking) return RT_OK;
-    HIP_TRY(c, hipEventSynchronize(c->parked_ready));
+    { StallTimer st("wait for the parked count"); HIP_TRY(c, hipEventSynchronize(c->parked_ready)); }
     uint32_t parked = c->h_parked[0];
     int cur = 0;
     for (uint32_t round = 0; parked != 0; ++round) {
@@ -1212,12 +1224,12 @@ int render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending& L)
         }
         p.slots = c->d_slots.ptr;
     }
-    if (int rc = ensure_dirs(c, p)) return rc;
-    if (tree) { if (int rc = ensure_columns(c, p)) return rc; }
+    { StallTimer st("ensure_dirs"); if (int rc = ensure_dirs(c, p)) return rc; }
+    if (tree) { StallTimer st("ensure_columns"); if (int rc = ensure_columns(c, p)) return rc; }
     const bool ordered = tree && rt_traversal_in_use(c) == RT_ORDER_FRONT_TO_BACK;
     // Units without a primary ray into the root box are not traced (a scene without spheres; the counting kernels trace all)
     const bool skip_empty = mode == RT_SCENE_MESH && c->settings.bounces != 0u && !c->stats;
-    if (skip_empty) { if (int rc = ensure_units(c, p, ordered)) return rc; }
+    if (skip_empty) { StallTimer st("ensure_units"); if (int rc = ensure_units(c, p, ordered)) return rc; }
     // (the number of listed units is read on the device; the host sizes the grid with it once it has arrived)
     const uint32_t n_traced_units = skip_empty && c->units_known ? c->n_list : p.n_units;
     const bool plain_tree = skip_empty && !c->settings.anti_aliasing && !p.halo;         // (see rt_ctx::empties_settled)
@@ -1248,6 +1260,7 @@ int render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending& L)
     // cost more than the wait): the one word is waited for here, after the unit classification has been queued behind it, so the
     // device has work while the host wakes up.  Once per view.
     if (tree && c->columns_pending) {
+        StallTimer st("wait for the column count");
         HIP_TRY(c, hipEventSynchronize(c->ev_columns));
         c->columns_pending = false; c->n_columns = c->h_view[0]; c->columns_known = true;
     }
@@ -1280,7 +1293,7 @@ int render_issue(rt_ctx* c, uint32_t frame_index, uint32_t n, rt_pending& L)
     if (timed) HIP_TRY(c, hipEventRecord(c->ev_start[ev], c->stream));
     c->last_grid_waves = grid * (rt_trace_block(mode) / 64u);
     bool parking = false;
-    if (int rc = trace_issue(c, p, mode, ordered, grid, timed ? c->ev_stop[ev] : nullptr, parking)) return rc;
+    { StallTimer st("trace_issue"); if (int rc = trace_issue(c, p, mode, ordered, grid, timed ? c->ev_stop[ev] : nullptr, parking)) return rc; }
     L.active = true; L.parking = parking; L.tree = tree; L.ordered = ordered; L.timed = timed; L.skip_empty = skip_empty; L.reuse = reuse;
     L.plain_tree = plain_tree; L.listed_only = listed_only; L.fused = fused; L.mode = mode; L.ev = ev; L.gx = gx; L.gy = gy;
     L.frame_index = frame_index; L.n = n;
@@ -1331,6 +1344,7 @@ int rt_render_frames(rt_ctx* c, uint32_t frame_index, uint32_t n)
     if (!c) return RT_E_ARG;
     if (int rc = render_checks(c, frame_index, n)) return rc;
     DeviceGuard g(c->device);
+    StallTimer whole("rt_render_frames");
     if (int rc = collect_time(c, false)) return rc;
     // sphere scenes: a lane keeps its pixel for all n frames, whatever n; tree scenes: at most RT_MAX_LAUNCH_FRAMES planes of slots
     const uint32_t per_launch = c->settings.scene_mode == RT_SCENE_SPHERES ? n : (uint32_t)RT_MAX_LAUNCH_FRAMES;
@@ -1585,6 +1599,7 @@ __attribute__((visibility("hidden"))) int rt_internal_render_issue(rt_ctx* c, ui
 {
     if (int rc = render_checks(c, frame_index, n)) return rc;
     DeviceGuard g(c->device);
+    StallTimer whole("rt_render_frames");
     if (int rc = collect_time(c, false)) return rc;
     return render_issue(c, frame_index, n, *L);
 }

@@ -53,6 +53,7 @@ class KDTree:
         self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 3)
         self.tris = np.ascontiguousarray(tris, np.uint32).reshape(-1, 3)
         assert len(self.tris) == num_tris and len(self.verts) == num_verts
+        self._free = lib().rt_host_kd_free          # (kept here: module globals may be gone when __del__ runs at interpreter exit)
         self._h = lib().rt_host_kd_build(ptr(self.verts), num_verts, ptr(self.tris), num_tris, max_nodes, nthreads)
         if not self._h:
             raise _capi.RtError("rt_host_kd_build failed (bad indices, or the node guard of %d was hit)" % max_nodes)
@@ -63,7 +64,7 @@ class KDTree:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().rt_host_kd_free(self._h)
+            self._free(self._h)
             self._h = None
 
     def getNumNodes(self):

@@ -28,8 +28,14 @@ def main():
         r = rt.Renderer(0); r.download = False
         st = r.GetSettings(); st.SceneMode, st.Bounces = cfg["mode"], cfg["bounces"]
         r.OnResize(cfg["w"], cfg["h"]); r.upload(scene, cam)
-        for f in range(1, 4):
-            r.render_only(f)
+        bench.settle_gc()                                   # (a full collection over the host copy of the scene takes ~50 ms)
+        # the device idles while the host builds the scene: render for half a second first
+        import time
+        t_end, f = time.perf_counter() + 0.5, 1
+        while time.perf_counter() < t_end:
+            r.render_only(f); f += 1
+            if f % 8 == 0:
+                r.sync()
         r.sync()
         print(json.dumps({"config": cid, "view_change": bench.view_change(r, scene, cam, cfg, torch, steps, kinds)}), flush=True)
         del r, scene
