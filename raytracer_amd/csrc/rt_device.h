@@ -34,6 +34,9 @@
 #define RT_PARK_WORDS 5            // float4 per parked path
 #define RT_MAX_LAUNCH_FRAMES 16    // tree scenes: Renders one launch can hold (a plane of per-pixel radiance slots each)
 #define RT_WALK_FETCH 6           /* float4 read per walk trip at most: up to three consecutive nodes or two leaf records */
+#ifndef RT_EXACT_REF_COOP
+#define RT_EXACT_REF_COOP 1       /* experiments: 0 = the last walks of a wave in the reference's order use the windowed walk of the front-to-back order */
+#endif
 #ifndef RT_TRIP_NODES
 #define RT_TRIP_NODES 2           /* node steps a lane makes from one read, while it keeps descending to the next node in memory (1..3) */
 #endif

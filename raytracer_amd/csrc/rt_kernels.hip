@@ -657,69 +657,100 @@ __device__ __forceinline__ bool walk_cooperative(const RtParams& p, const float4
 // KDTreeCPU::intersect's own sequence of decisions for one ray (reference order, every box pruned against the closest hit of
 // the moment it is reached, a hit accepted only when strictly closer), made by the whole wave.  A window of 64 consecutive
 // nodes of the reference preorder is decided with the closest t known at its start; that is exactly what the one-lane walk
-// would have used up to the first leaf of the window that finds a closer hit.  The lane of that leaf finishes its leaf in
-// order, its result becomes the closest hit, and the next window starts right behind it; lanes behind it are recomputed.
-// A ray accepts a closer hit a few dozen times at most, so the walk takes about (nodes spanned / 64) + (hits accepted) windows
-// instead of one dependent read per node.  Used for the rays whose front-to-back walk met a near tie.
-template <bool STATS>
-__device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3 O, F3 D, F3 invD, uint32_t lane, Hit& hit,
+// would have used up to the first leaf of the window that finds a closer hit.  The reached leaves are tested in preorder, four
+// at a time with sixteen lanes each (one record per lane and pass); the first of them that holds a closer hit ends the window:
+// the closest of its hits (the earliest record among equals, as the strict comparison of the sequential loop leaves it) becomes
+// the closest hit, the next window starts right behind that leaf, and what the lanes behind it decided or tested is discarded
+// and recomputed.  A ray accepts a closer hit a few dozen times at most, so the walk takes about (nodes spanned / 64) + (hits
+// accepted) windows instead of one dependent read per node.  Used for the rays whose front-to-back walk met a near tie, for the
+// rays the short forms of the tests are not for, and for the last walks of a wave in the reference's order.
+// `start`, hit: the node cursor and the closest hit of a walk in the reference's order that this one continues (0 and no hit: the
+// whole walk; all arguments wave-uniform).  PLAIN: the short forms of the box and triangle tests (see slab_plain_ray).
+template <bool STATS, bool PLAIN>
+__device__ __forceinline__ void walk_reference_cooperative(const RtParams& p, F3 O, F3 D, F3 invD, uint32_t lane, uint32_t start, Hit& hit,
                                                            uint32_t& n_nodes_visited, uint32_t& n_tris_tested)
 {
-    float t_cur = FLT_MAX, hu = 0.0f, hv = 0.0f;            // wave-uniform
-    int32_t tri = -1;
-    bool detected = false;                                  // wave-uniform
-    uint32_t base = 0, killed_to = 0;
+    float t_cur = hit.t, hu = hit.u, hv = hit.v;            // wave-uniform
+    int32_t tri = hit.id >= 0 ? hit.id : -1;
+    bool detected = hit.id == RT_HIT_DETECTED;              // wave-uniform
     const uint32_t end = p.n_nodes;
+    start = checked(p, start, end + 1u, 17);
+    uint32_t base = start, killed_to = start;
     while (base < end) {
         const uint32_t j = base + lane;
         const bool valid = j < end;
         float4 n0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), n1 = n0;
         if (valid) { n0 = p.nodes[2 * (size_t)j]; n1 = p.nodes[2 * (size_t)j + 1]; }
         float tNear;
-        const bool box = slab_test(n0, n1, O, invD, tNear);
+        const bool box = slab_test_t<PLAIN>(n0, n1, O, invD, tNear);
         const bool descend = valid && box && !(tNear > t_cur);
         const uint32_t skip = __float_as_uint(n0.w);
         const int32_t leaf_first = (int32_t)__float_as_uint(n1.w);
         const uint32_t pm = wave_prefix_max((valid && !descend) ? skip : 0u);
         const uint32_t limit = pm > killed_to ? pm : killed_to;
         const bool reached = valid && j >= limit;           // exact for the nodes that are not rejected, which is all that is asked below
-        float lt = t_cur, lu = 0.0f, lv = 0.0f;
-        int32_t ltri = -1;
-        bool closer = false, succeeded = false;
-        uint32_t tested = 0;
-        if (reached && descend && leaf_first >= 0) {
-            const float4* rec = p.leafrecs + 3 * (size_t)checked(p, (uint32_t)leaf_first, p.n_refs, 16);
-            float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            for (;;) {
-                const float4 q0 = rec[3], q1 = rec[4], q2 = rec[5];
-                rec += 3;
-                ++tested;
-                const uint32_t tag = __float_as_uint(r2.y);
-                float tt, u, v;
-                if (tri_test(r0, r1, r2, O, D, tt, u, v)) {
-                    succeeded = true;
-                    if (tt < lt) { lt = tt; ltri = (int32_t)(tag & 0x7FFFFFFFu); lu = u; lv = v; closer = true; }
-                }
-                if (tag & 0x80000000u) break;
-                r0 = q0; r1 = q1; r2 = q2;
-            }
-        }
-        const unsigned long long found = __ballot(closer);
+        unsigned long long leaves = __ballot(reached && descend && leaf_first >= 0);
         uint32_t upto = 64u;                                // lanes of this window whose decisions stand
-        if (found != 0ull) {
-            const int f = __ffsll((long long)found) - 1;
-            t_cur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lt), f));
-            hu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lu), f));
-            hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv), f));
-            tri = __builtin_amdgcn_readlane(ltri, f);
-            upto = (uint32_t)f + 1u;
+        while (leaves != 0ull) {
+            uint32_t group_first = RT_NO_REC, group_node = 0;       // this 16-lane group's leaf: first record, lane of the window that holds it
+#pragma unroll
+            for (uint32_t g = 0; g < 4u; ++g) {
+                if (leaves != 0ull) {
+                    const int src = __ffsll((long long)leaves) - 1;
+                    leaves &= leaves - 1ull;
+                    const uint32_t first = checked(p, (uint32_t)__builtin_amdgcn_readlane(leaf_first, src), p.n_refs, 16);
+                    if ((lane >> 4) == g) { group_first = first; group_node = (uint32_t)src; }
+                }
+            }
+            float lt = __builtin_inff(), lu = 0.0f, lv = 0.0f;       // this lane's closest hit below t_cur
+            int32_t ltri = -1;
+            uint32_t lrec = RT_NO_REC, tested = 0;
+            bool succeeded = false;
+            bool open = group_first != RT_NO_REC;
+            uint32_t rec_index = group_first + (lane & 15u);
+            while (__ballot(open) != 0ull) {
+                const uint32_t at = rec_index < p.n_refs ? rec_index : p.n_refs - 1u;
+                float4 r0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), r1 = r0, r2 = r0;
+                if (open) { const float4* rec = p.leafrecs + 3 * (size_t)at; r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; }
+                const uint32_t tag = __float_as_uint(r2.y);
+                const unsigned long long ends = __ballot(open && (tag & 0x80000000u) != 0u);
+                const uint32_t group_ends = (uint32_t)(ends >> (lane & 48u)) & 0xFFFFu;
+                const bool counts = open && rec_index < p.n_refs && (group_ends & ((1u << (lane & 15u)) - 1u)) == 0u;
+                if (counts) ++tested;
+                float tt, u, v;
+                if (tri_test_t<PLAIN>(r0, r1, r2, O, D, tt, u, v) && counts) {
+                    succeeded = true;
+                    if (tt < t_cur && tt < lt) { lt = tt; lrec = rec_index; ltri = (int32_t)(tag & 0x7FFFFFFFu); lu = u; lv = v; }
+                }
+                if (group_ends != 0u) open = false;
+                rec_index += 16u;
+            }
+            // the first leaf (lowest group) with a closer hit, and the closest hit of that leaf
+            const unsigned long long closer = __ballot(ltri >= 0);
+            uint32_t groups_standing = 4u;
+            if (closer != 0ull) {
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {     // within the 16-lane groups: smallest t, then earliest record
+                    const float ot = __shfl_xor(lt, off); const uint32_t orec = __shfl_xor(lrec, off);
+                    const int32_t otri = __shfl_xor(ltri, off); const float ou = __shfl_xor(lu, off), ov = __shfl_xor(lv, off);
+                    if (ot < lt || (ot == lt && orec < lrec)) { lt = ot; lrec = orec; ltri = otri; lu = ou; lv = ov; }
+                }
+                const int f = ((__ffsll((long long)closer) - 1) >> 4) << 4;      // first lane of that group
+                t_cur = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lt), f));
+                hu = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lu), f));
+                hv = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lv), f));
+                tri = __builtin_amdgcn_readlane(ltri, f);
+                upto = (uint32_t)__builtin_amdgcn_readlane((int)group_node, f) + 1u;
+                groups_standing = ((uint32_t)f >> 4) + 1u;
+                leaves = 0ull;                              // what lies behind that leaf is decided again, with the new t
+            }
+            if (__ballot(succeeded && (lane >> 4) < groups_standing) != 0ull) detected = true;     // (only the leaves whose tests stand)
+            if (STATS && (lane >> 4) < groups_standing) n_tris_tested += tested;
         }
-        if (__ballot(succeeded && lane < upto) != 0ull) detected = true;     // (only the lanes whose decisions stand)
         if (STATS) {
             uint32_t before = __shfl_up(pm, 1);             // rejected subtrees' ends over the lanes before this one
             if (lane == 0) before = 0u;
             if (lane < upto && valid && j >= (before > killed_to ? before : killed_to)) n_nodes_visited++;
-            if (lane < upto) n_tris_tested += tested;
         }
         const uint32_t kills = (uint32_t)__builtin_amdgcn_readlane((int)pm, (int)upto - 1);
         if (kills > killed_to) killed_to = kills;
@@ -1851,11 +1882,12 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
     __shared__ PathPool pool;                               // the mixed mode reads its table from here (trace_spheres_lds)
     // the counting kernels keep every path in the lane that started it (their per-wave clocks and trip counts describe the plain walk)
     constexpr bool SHARE = RT_SHARE != 0 && !STATS;
-    // The timed front-to-back kernels make their box tests in the short form (slab_test_t<true>), which is exact for rays that
-    // cannot meet a NaN in them (slab_plain_ray).  The few other rays (a zero or denormal direction component in y or z, an origin
-    // beyond 2^60, a tree with boxes beyond 2^60) never enter that walk: the wave makes the reference's own walk for them, with the
-    // compare+select forms, as it does for near ties.
-    constexpr bool PLAIN = RT_PLAIN_SLAB != 0 && ORDERED && RT_NEAR_TIES != 0 && !STATS;
+    // The timed kernels make their box tests in the short form (slab_test_t<true>), which is exact for rays that cannot meet a
+    // NaN in them (slab_plain_ray).  The few other rays (a zero or denormal direction component in y or z, an origin beyond
+    // 2^60, a tree with boxes beyond 2^60) never enter that walk: the wave makes the reference's own walk for them, with the
+    // compare+select forms, as it does for the near ties of the front-to-back order (REDO: the kernel holds that route).
+    constexpr bool PLAIN = RT_PLAIN_SLAB != 0 && !STATS;
+    constexpr bool REDO = PLAIN || (ORDERED && RT_NEAR_TIES != 0);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const bool spheres_in_lds = RT_SPHERE_LDS_LOOP && MODE == RT_MODE_BOTH && p.n_spheres <= RT_LDS_SPHERES;
@@ -2152,7 +2184,7 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
 
         // ---- a slice of the walks (KDTreeCPU.cpp:640-708): one node or one leaf record per lane and trip
         {
-            if (ORDERED && RT_NEAR_TIES) {                  // rays that met a near tie: the reference's own walk, by the whole wave
+            if (REDO) {                                     // rays that met a near tie, rays the short forms are not for: the reference's own walk, by the whole wave
                 unsigned long long again = __ballot(phase == PH_REDO);
                 while (again != 0ull) {
                     const int src = __ffsll((long long)again) - 1;
@@ -2160,9 +2192,9 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                     const F3 O = f3(__shfl(s.O.x, src), __shfl(s.O.y, src), __shfl(s.O.z, src));
                     const F3 D = f3(__shfl(s.D.x, src), __shfl(s.D.y, src), __shfl(s.D.z, src));
                     const F3 invD = f3(__shfl(winvD.x, src), __shfl(winvD.y, src), __shfl(winvD.z, src));
-                    Hit h;
+                    Hit h; h.t = FLT_MAX; h.id = -1; h.u = 0.0f; h.v = 0.0f;
                     uint32_t cn = 0, ct = 0;
-                    walk_reference_cooperative<STATS>(p, O, D, invD, lane, h, cn, ct);
+                    walk_reference_cooperative<STATS, false>(p, O, D, invD, lane, 0u, h, cn, ct);
                     n_nodes += cn; n_tris += ct;
                     if ((int)lane == src) { th = h; phase = PH_SHADE; }
                 }
@@ -2190,10 +2222,16 @@ __device__ __forceinline__ void tree_body(const RtParams& p)
                         h.t = __shfl(th.t, src); h.id = __shfl(th.id, src); h.u = __shfl(th.u, src); h.v = __shfl(th.v, src);
                         uint32_t best = __shfl(wbest, src);
                         const uint32_t first = __shfl(wnode, src);
-                        const float4* nodes = p.nodes + 2 * ((size_t)__shfl(woct, src) * (size_t)p.n_nodes);
-                        const float tol = ORDERED ? __shfl(wtol, src) : 0.0f;
-                        const float cap = __shfl(sphere_cap(), src);
-                        const bool near_tie = walk_cooperative<ORDERED, PLAIN>(p, nodes, O, D, invD, first, lane, tol, cap, h, best);
+                        bool near_tie = false;
+                        if (ORDERED || !RT_EXACT_REF_COOP) {
+                            const float4* nodes = p.nodes + 2 * ((size_t)__shfl(woct, src) * (size_t)p.n_nodes);
+                            near_tie = walk_cooperative<ORDERED, PLAIN>(p, nodes, O, D, invD, first, lane, ORDERED ? __shfl(wtol, src) : 0.0f, __shfl(sphere_cap(), src), h, best);
+                        } else {
+                            // the reference's order: the rest of the walk with its own decisions, every box pruned against the closest hit
+                            // of the moment it is reached (windows decided with an older t would visit leaves the reference prunes)
+                            uint32_t cn = 0, ct = 0;
+                            walk_reference_cooperative<false, PLAIN>(p, O, D, invD, lane, first, h, cn, ct);
+                        }
                         if ((int)lane == src) {
                             th = h; wbest = best; wnode = end;
                             wprune = ORDERED && RT_NEAR_TIES ? h.t + (wtol + p.tie_rel * h.t) : h.t;
