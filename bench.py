@@ -15,7 +15,7 @@ box's host cores.  Beside the one-Render-per-launch figures the line carries
   * `throughput_mode`: the same frames as launches of 16 Renders (rt_render_frames), what a progressive accumulation uses;
   * `with_d2h`: ms per Render including the hand-off of the RGBA32F frame to host memory (rt_map_image, and the pipelined
     variant that copies frame k beside the trace of frame k + 1) -- what the drop-in Renderer::Render costs;
-  * `other_configs` (one-GPU default run only): the tree configurations 3 and 4, measured the same way in the same process.
+  * `other_configs` (one-GPU default run only): the tree configurations 3, 4 and 6 (Cornell-box-class OBJ), measured the same way in the same process.
 """
 import argparse
 import gc
@@ -513,7 +513,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-configs", action="store_true", help="skip the tree configurations 3 and 4 of the default one-GPU run")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the tree configurations 3, 4 and 6 of the default one-GPU run")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--profile", default="", choices=["", "single", "throughput"],
                     help="for profiler passes: only one-Render-per-launch steps, or only launches of 16 Renders (timed launches of one kind "
@@ -652,7 +652,7 @@ def main():
             # throughput mode each; counters, event times and rooflines as for the main configuration)
             del r
             others = []
-            for cid, steps in ((3, 32), (4, 16)):
+            for cid, steps in ((3, 32), (4, 16), (6, 32)):
                 try:
                     rec, _s, _c, rr = run_single(cid, steps, 3, args.order, torch, local_rank)
                     del rr, _s

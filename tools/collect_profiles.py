@@ -13,7 +13,7 @@ traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 # the SIMDs can issue), from the same passes
 issue_path = os.path.join(root, "profiles", "issue.json")
 issue = json.load(open(issue_path)) if os.path.exists(issue_path) else {}
-for cfg in (1, 2, 3, 4, 5):
+for cfg in (1, 2, 3, 4, 5, 6):
     for kind in ("single", "throughput"):
         d = os.path.join(root, "gpurun_out", "prof_cfg%d_%s" % (cfg, kind))
         summ = d + "_summary.json"
@@ -35,7 +35,9 @@ for cfg in (1, 2, 3, 4, 5):
             n_main = b["roofline"]["launches"] + (b["warmup"] if kind == "single" else 0)
         for k, cs in s["counters"].items():
             # the kernels the benchmark times: no counting, front-to-back walk (the reference-order walk runs once, for the counts)
-            timed = "rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k
+            # (or, where RT_ORDER_AUTO picks the reference's order -- config 6 --, the timed reference-order kernel)
+            timed = ("rt_trace_spheres_kernel<false" in k or "rt_trace_kernel<0, false, true>" in k or "rt_trace_kernel<2, false, true>" in k or
+                     "rt_trace_kernel<0, false, false>" in k or "rt_trace_kernel<2, false, false>" in k)
             if timed and "SQ_INSTS_VALU" in cs and "SQ_INSTS_SALU" in cs:
                 key = "config%d" % cfg if kind == "single" else "config%d_x16" % cfg
                 calls = cs["SQ_INSTS_VALU"]["launches"]
