@@ -160,3 +160,28 @@ def test_builder_guard_stops_the_divergent_case():
     tris = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)], np.uint32)
     with pytest.raises(_capi.RtError):
         rt.KDTree(len(tris), tris, len(verts), verts, max_nodes=200000, nthreads=2)
+
+
+def test_host_side_under_the_sanitizers(tmp_path):
+    """rt_host.cpp (KD builder on 1, 3 and 8 threads, flat view, refusal of bad indices, camera) compiled with
+    -fsanitize=address,undefined and with -fsanitize=thread and driven by tests/cpp/host_sanitizers.cpp: no report, the same
+    tree from every thread count."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for kind in ("address,undefined", "thread"):
+        exe = str(tmp_path / ("san_" + kind.split(",")[0]))
+        cc = subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + kind, "-fno-omit-frame-pointer", "-I" + os.path.join(root, "include"),
+                             os.path.join(root, "tests", "cpp", "host_sanitizers.cpp"), os.path.join(root, "raytracer_amd", "csrc", "rt_host.cpp"),
+                             "-o", exe, "-pthread"], capture_output=True, text=True)
+        assert cc.returncode == 0, cc.stderr[-2000:]
+        run = subprocess.run([exe, "2"], capture_output=True, text=True, timeout=600)
+        assert run.returncode == 0, (run.stdout[-1000:], run.stderr[-3000:])
+        assert "WARNING" not in run.stderr and "ERROR" not in run.stderr and "runtime error" not in run.stderr, run.stderr[-3000:]
+        lines = [l for l in run.stdout.splitlines() if l.startswith("round ")]
+        assert len(lines) == 6
+        for r in range(2):                                     # the same tree from 1, 3 and 8 threads
+            assert len({l.split(":", 1)[1] for l in lines[3 * r: 3 * r + 3]}) == 1
+        assert "bad index: refused" in run.stdout
