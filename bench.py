@@ -537,6 +537,12 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    # Rehearsal on a box with fewer GPUs than ranks: RT_BENCH_DEVICE=<n> puts every rank on that device and RT_BENCH_BACKEND=gloo moves
+    # the collectives through host memory (RCCL refuses two ranks on one GPU).  The numbers of such a run mean nothing; the code path
+    # of every rank is the one `--gpus N` runs.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    if os.environ.get("RT_BENCH_DEVICE"):
+        local_rank = int(os.environ["RT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     # RT_BENCH_FORCE_DIST=1 runs the multi-GPU code path (process group, RCCL sum, rank-0 resolve) even with one rank,
     # so it can be rehearsed on a one-GPU box
@@ -544,7 +550,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = CONFIGS[args.config]
     w, h, K, W = cfg["w"], cfg["h"], args.steps, args.warmup
@@ -628,6 +637,8 @@ def main():
                        "empty_unit_rays_per_frame": cnt.empty_unit_rays / K, "image": "resident in HBM (no D2H in the timed region)"},
             "roofline": roof,
         }
+        if os.environ.get("RT_BENCH_DEVICE") or backend != "nccl":
+            out["rehearsal"] = "ranks share device %d, collectives over %s: a check of the code path, not a measurement" % (local_rank, backend)
         if args.profile:
             out["profile"] = args.profile + (": %d Renders per launch in the timed region" % per_launch)
         if world == 1 and not use_dist and not args.profile:

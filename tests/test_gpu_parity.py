@@ -1006,6 +1006,27 @@ def test_bench_distributed_code_path_with_one_rank():
     assert d["roofline"]["frac"] > 0 and d["unit"] == "Mrays/s"
 
 
+def test_bench_with_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 as the driver launches it, both ranks on device 0 and the collectives over gloo (RCCL refuses two ranks on one
+    GPU): every rank's code path -- its frame indices, the sum onto rank 0, the maximum of the times, the one JSON line -- runs; the
+    rays of the line are those of both ranks' frames."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", RT_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--config", "1"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["split"] == "sample" and d["scaling"] == "weak" and "rehearsal" in d
+    # 8 frames of the 1280x720 sphere scene: 3.38 M rays each
+    assert 7.5 * 3.3e6 < d["value"] * d["ms_per_step"] * 1e3 * 4 < 8.5 * 3.5e6
+    assert "cpu_baseline" not in d                           # the oracle is timed beside the one-GPU run only
+
+
 # ---- the drop-in itself: RendererHIP with the reference's own Scene / Camera / KDTreeCPU ------------------------------------------
 @pytest.mark.parametrize("use_spheres,contexts", [(1, 1), (0, 1), (0, 3)], ids=["spheres", "mesh", "mesh-3-contexts"])
 def test_renderer_hip_with_reference_host_types(orc, tmp_path, use_spheres, contexts):
